@@ -1,0 +1,751 @@
+// c1_api.hip -- host side of libcarta1_hip.so: the C ABI of include/carta1_hip.h.
+// Contexts, table upload, workspace, chunking of large batches, stateful streams, profiling events.
+// Compiled with -ffp-contract=off: the twiddle recurrence and the normalisation table below are part
+// of the reference's numerics (codec/transforms/fft.js:62-64, codec/coding/quantization.js:42-44).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "c1_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+#include "c1_default_tables.inc"
+
+thread_local std::string g_error;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(C1_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+std::mutex g_tables_mutex;
+bool g_tables_custom = false;
+c1_tables g_tables;
+
+void default_tables(c1_tables *t) {
+  memcpy(t->scale_factors, C1D_SCALE_FACTORS, sizeof t->scale_factors);
+  memcpy(t->window_short, C1D_WINDOW_SHORT, sizeof t->window_short);
+  memcpy(t->mdct_fwd64, C1D_MDCT_FWD64, sizeof t->mdct_fwd64);
+  memcpy(t->mdct_fwd256, C1D_MDCT_FWD256, sizeof t->mdct_fwd256);
+  memcpy(t->mdct_fwd512, C1D_MDCT_FWD512, sizeof t->mdct_fwd512);
+  memcpy(t->mdct_inv64, C1D_MDCT_INV64, sizeof t->mdct_inv64);
+  memcpy(t->mdct_inv256, C1D_MDCT_INV256, sizeof t->mdct_inv256);
+  memcpy(t->mdct_inv512, C1D_MDCT_INV512, sizeof t->mdct_inv512);
+  memcpy(t->fft_w, C1D_FFT_W, sizeof t->fft_w);
+  t->log1p_10 = C1D_LOG1P_10;
+}
+
+// QMF prototype (codec/core/constants.js:74-107): `new Float32Array([...])` rounds the decimal
+// literals decimal -> double -> float; the 48-tap window is 2 * prototype, mirrored; EVEN = window[2j].
+void qmf_even_taps(double out[24]) {
+  static const double proto[24] = {
+      -0.00001461907, -0.00009205479, -0.000056157569, 0.00030117269, 0.0002422519, -0.00085293897,
+      -0.0005205574,  0.0020340169,   0.00078333891,   -0.0042153862, -0.00075614988, 0.0078402944,
+      -0.000061169922, -0.01344162,   0.0024626821,    0.021736089,   -0.007801671,  -0.034090221,
+      0.01880949,     0.054326009,    -0.043596379,    -0.099384367,  0.13207909,    0.46424159};
+  float window[48];
+  for (int i = 0; i < 24; i++) {
+    const float c = (float)proto[i];
+    window[i] = (float)((double)c * 2.0);
+    window[47 - i] = window[i];
+  }
+  for (int j = 0; j < 24; j++) out[j] = (double)window[2 * j];
+}
+
+void build_device_tables(const c1_tables &t, C1DevTables *d) {
+  memset(d, 0, sizeof *d);
+  qmf_even_taps(d->tap_e);
+  for (int j = 0; j < 24; j++) d->tap_o[j] = d->tap_e[23 - j];
+  memcpy(d->window, t.window_short, sizeof d->window);
+  memcpy(d->mdct_fwd64, t.mdct_fwd64, sizeof d->mdct_fwd64);
+  memcpy(d->mdct_fwd256, t.mdct_fwd256, sizeof d->mdct_fwd256);
+  memcpy(d->mdct_fwd512, t.mdct_fwd512, sizeof d->mdct_fwd512);
+  memcpy(d->mdct_inv64, t.mdct_inv64, sizeof d->mdct_inv64);
+  memcpy(d->mdct_inv256, t.mdct_inv256, sizeof d->mdct_inv256);
+  memcpy(d->mdct_inv512, t.mdct_inv512, sizeof d->mdct_inv512);
+  // twiddle recurrence of FFT.fft (fft.js:44-64): starts at (1,0), advanced by a complex multiply in
+  // double, unfused; it does not depend on the data, so it is tabulated once per stride
+  int stage = 0;
+  for (int h = 1; h <= 128; h <<= 1, stage++) {
+    const double wr = t.fft_w[stage][0], wi = t.fft_w[stage][1];
+    double tr = 1.0, ti = 0.0;
+    for (int k = 0; k < h; k++) {
+      d->fft_tw[h - 1 + k][0] = tr;
+      d->fft_tw[h - 1 + k][1] = ti;
+      const double nr = tr * wr - ti * wi;
+      ti = tr * wi + ti * wr;
+      tr = nr;
+    }
+  }
+  memcpy(d->scale_factors, t.scale_factors, sizeof d->scale_factors);
+  for (int s = 0; s < 64; s++)
+    for (int wl = 0; wl < 16; wl++) {
+      const int bits = wl == 0 ? 0 : wl + 1;
+      const int range = bits ? (1 << (bits - 1)) - 1 : 0;
+      d->norm[s * 16 + wl] = (double)range / t.scale_factors[s];  // quantization.js:42-44
+    }
+  d->log1p10 = t.log1p_10;
+}
+
+// rank table of the Float32 heap priorities (bitallocation.js:226-231, 267-269)
+int build_encode_opts(const c1_encode_options &o, C1DevEncOpts *d) {
+  memset(d, 0, sizeof *d);
+  for (int i = 0; i < 64; i++) {
+    if (!std::isfinite(o.biased_scale_factors[i]) || o.biased_scale_factors[i] < 0)
+      return fail(C1_ERR_ARG, "biased_scale_factors[%d] is not a finite non-negative number", i);
+    d->biased[i] = o.biased_scale_factors[i];
+  }
+  if (std::isnan(o.transient_threshold)) return fail(C1_ERR_ARG, "transient_threshold is NaN");
+  d->threshold = o.transient_threshold;
+  const bool detect = o.fixed_block_modes[0] < 0;
+  for (int b = 0; b < 3; b++) {
+    const int m = o.fixed_block_modes[b];
+    if (detect) { d->modes[b] = -1; continue; }
+    if (m < 0 || m > (b == 2 ? 3 : 2))
+      return fail(C1_ERR_ARG, "fixed_block_modes[%d] = %d is outside 0..%d", b, m, b == 2 ? 3 : 2);
+    d->modes[b] = m;
+  }
+  float pri[64 * 15];
+  std::vector<float> uniq;
+  for (int s = 1; s < 64; s++)
+    for (int wl = 0; wl < 15; wl++) {
+      const int b0 = wl == 0 ? 0 : wl + 1, b1 = wl + 2;
+      const double ddf = wl == 0 ? 2.0 - std::ldexp(1.0, -b1) : std::ldexp(1.0, -b0) - std::ldexp(1.0, -b1);
+      const double dbits = (double)(b1 - b0);
+      pri[s * 15 + wl] = (float)(d->biased[s] * ddf / dbits);
+      uniq.push_back(pri[s * 15 + wl]);
+    }
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  for (int s = 1; s < 64; s++)
+    for (int wl = 0; wl < 15; wl++) {
+      const auto it = std::lower_bound(uniq.begin(), uniq.end(), pri[s * 15 + wl]);
+      d->rank[s * 16 + wl] = (uint16_t)(1 + (it - uniq.begin()));
+    }
+  return C1_OK;
+}
+
+struct Timing {
+  hipEvent_t start, stop;
+  int kind;
+};
+enum { K_ANALYSIS = 0, K_ALLOCATE, K_PACK, K_DECODE, K_KINDS };
+const char *const kKindNames[K_KINDS] = {"analysis", "allocate", "pack", "decode"};
+
+}  // namespace
+
+struct c1_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  C1DevTables *d_tables = nullptr;
+  C1DevEncOpts *d_opts = nullptr;
+  c1_encode_options last_opts;
+  bool have_opts = false;
+  // workspace for one chunk
+  int64_t ws_units = 0;
+  float *d_coefs = nullptr;
+  uint8_t *d_side = nullptr;
+  uint8_t *d_alloc = nullptr;
+  int64_t chunk_frames = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<Timing> timings;
+  std::vector<hipEvent_t> event_pool;
+  double ms[K_KINDS] = {0, 0, 0, 0};
+  int launches[K_KINDS] = {0, 0, 0, 0};
+  // scratch for host-resident calls
+  void *d_io = nullptr;
+  size_t d_io_bytes = 0;
+};
+
+namespace {
+
+int ctx_bind(c1_ctx *ctx) {
+  if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return C1_OK;
+}
+
+int ensure_workspace(c1_ctx *ctx, int64_t units) {
+  if (units <= ctx->ws_units) return C1_OK;
+  if (ctx->d_coefs) { hipFree(ctx->d_coefs); hipFree(ctx->d_side); hipFree(ctx->d_alloc); }
+  ctx->d_coefs = nullptr; ctx->d_side = nullptr; ctx->d_alloc = nullptr; ctx->ws_units = 0;
+  HIP_TRY(hipMalloc(&ctx->d_coefs, (size_t)units * 512 * sizeof(float)));
+  HIP_TRY(hipMalloc(&ctx->d_side, (size_t)units * kSideBytes));
+  HIP_TRY(hipMalloc(&ctx->d_alloc, (size_t)units * kAllocBytes));
+  ctx->ws_units = units;
+  return C1_OK;
+}
+
+int ensure_io(c1_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->d_io_bytes) return C1_OK;
+  if (ctx->d_io) hipFree(ctx->d_io);
+  ctx->d_io = nullptr; ctx->d_io_bytes = 0;
+  HIP_TRY(hipMalloc(&ctx->d_io, bytes));
+  ctx->d_io_bytes = bytes;
+  return C1_OK;
+}
+
+int upload_opts(c1_ctx *ctx, const c1_encode_options *opts) {
+  if (!opts) return fail(C1_ERR_ARG, "options are NULL");
+  if (ctx->have_opts && memcmp(&ctx->last_opts, opts, sizeof *opts) == 0) return C1_OK;
+  C1DevEncOpts h;
+  const int rc = build_encode_opts(*opts, &h);
+  if (rc) return rc;
+  // the previous options may still be in use by kernels queued on the stream
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(ctx->d_opts, &h, sizeof h, hipMemcpyHostToDevice));
+  ctx->last_opts = *opts;
+  ctx->have_opts = true;
+  return C1_OK;
+}
+
+hipEvent_t take_event(c1_ctx *ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+struct ScopedTiming {
+  c1_ctx *ctx;
+  Timing t;
+  bool on;
+  ScopedTiming(c1_ctx *c, int kind) : ctx(c), on(c->profiling) {
+    if (!on) return;
+    t.kind = kind;
+    t.start = take_event(ctx);
+    t.stop = take_event(ctx);
+    hipEventRecord(t.start, ctx->stream);
+  }
+  ~ScopedTiming() {
+    if (!on) return;
+    hipEventRecord(t.stop, ctx->stream);
+    ctx->timings.push_back(t);
+  }
+};
+void reset_timings(c1_ctx *ctx) {
+  for (auto &t : ctx->timings) { ctx->event_pool.push_back(t.start); ctx->event_pool.push_back(t.stop); }
+  ctx->timings.clear();
+  for (int k = 0; k < K_KINDS; k++) { ctx->ms[k] = 0; ctx->launches[k] = 0; }
+}
+int collect_timings(c1_ctx *ctx) {
+  if (ctx->timings.empty()) return C1_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto &t : ctx->timings) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+    ctx->ms[t.kind] += ms;
+    ctx->launches[t.kind]++;
+    ctx->event_pool.push_back(t.start);
+    ctx->event_pool.push_back(t.stop);
+  }
+  ctx->timings.clear();
+  return C1_OK;
+}
+
+int check_channels(int channels) {
+  if (channels != 1 && channels != 2) return fail(C1_ERR_ARG, "channels must be 1 or 2, got %d", channels);
+  return C1_OK;
+}
+
+int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                       const c1_encode_options *opts, uint8_t *units, float *bands, float *coefs_tap,
+                       uint8_t *side_tap, uint8_t *alloc_tap) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
+  if (halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "halo_frames must be 0, 1 or 2");
+  if (!pcm) return fail(C1_ERR_ARG, "pcm is NULL");
+  for (int c = 0; c < channels; c++) {
+    if (!pcm[c] && frames > 0) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    if ((uintptr_t)pcm[c] & 15) return fail(C1_ERR_ARG, "pcm[%d] must be 16-byte aligned on the device", c);
+  }
+  if ((rc = upload_opts(ctx, opts))) return rc;
+  if (ctx->profiling) reset_timings(ctx);
+  if (frames == 0) return C1_OK;
+  const bool detect = opts->fixed_block_modes[0] < 0;
+  const int64_t chunk = ctx->chunk_frames;
+  const bool taps = coefs_tap || side_tap || alloc_tap;
+  if (!taps && (rc = ensure_workspace(ctx, std::min(frames, chunk) * channels))) return rc;
+  if (taps && (!coefs_tap || !side_tap || !alloc_tap)) return fail(C1_ERR_ARG, "coefs, side and alloc taps must be given together");
+  for (int64_t f0 = 0; f0 < frames; f0 += taps ? frames : chunk) {
+    const int64_t n = taps ? frames : std::min(chunk, frames - f0);
+    C1EncodeLaunch L;
+    memset(&L, 0, sizeof L);
+    for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c] + f0 * 512;
+    L.channels = channels;
+    L.frames = n;
+    L.halo_frames = (int)std::min<int64_t>(2, f0 + halo_frames);
+    L.tables = ctx->d_tables;
+    L.opts = ctx->d_opts;
+    L.coefs = taps ? coefs_tap : ctx->d_coefs;
+    L.side = taps ? side_tap : ctx->d_side;
+    L.alloc = taps ? alloc_tap : ctx->d_alloc;
+    L.bands = bands ? bands + f0 * channels * 512 : nullptr;
+    L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
+    { ScopedTiming t(ctx, K_ANALYSIS); c1k_launch_analysis(L, detect, ctx->stream); }
+    { ScopedTiming t(ctx, K_ALLOCATE); c1k_launch_allocate(L, ctx->stream); }
+    if (L.units) { ScopedTiming t(ctx, K_PACK); c1k_launch_pack(L, ctx->stream); }
+  }
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+// xorshift32 as a GF(2) linear map: column form of T^n, used to jump the generator
+struct XsMatrix {
+  uint32_t col[32];
+  uint32_t apply(uint32_t s) const {
+    uint32_t r = 0;
+    for (int b = 0; b < 32; b++) if ((s >> b) & 1u) r ^= col[b];
+    return r;
+  }
+};
+uint32_t xs_step(uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+XsMatrix xs_power(uint64_t n) {
+  XsMatrix result, base;
+  for (int b = 0; b < 32; b++) { result.col[b] = 1u << b; base.col[b] = xs_step(1u << b); }
+  while (n) {
+    if (n & 1) { XsMatrix r; for (int b = 0; b < 32; b++) r.col[b] = base.apply(result.col[b]); result = r; }
+    XsMatrix sq;
+    for (int b = 0; b < 32; b++) sq.col[b] = base.apply(base.col[b]);
+    base = sq;
+    n >>= 1;
+  }
+  return result;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int c1_abi_version(void) { return C1_ABI_VERSION; }
+const char *c1_last_error(void) { return g_error.c_str(); }
+
+int c1_device_count(int *count) {
+  if (!count) return fail(C1_ERR_ARG, "count is NULL");
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(C1_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return C1_OK;
+}
+
+int c1_get_default_tables(c1_tables *out) {
+  if (!out) return fail(C1_ERR_ARG, "out is NULL");
+  default_tables(out);
+  return C1_OK;
+}
+
+int c1_set_tables(const c1_tables *tables) {
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  if (!tables) { g_tables_custom = false; return C1_OK; }
+  const double *p = reinterpret_cast<const double *>(tables);
+  for (size_t i = 0; i < sizeof(c1_tables) / sizeof(double); i++)
+    if (!std::isfinite(p[i])) return fail(C1_ERR_ARG, "table entry %zu is not finite", i);
+  g_tables = *tables;
+  g_tables_custom = true;
+  return C1_OK;
+}
+
+int c1_default_encode_options(c1_encode_options *out) {
+  if (!out) return fail(C1_ERR_ARG, "out is NULL");
+  memset(out, 0, sizeof *out);
+  c1_tables t;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    if (g_tables_custom) t = g_tables; else default_tables(&t);
+  }
+  memcpy(out->biased_scale_factors, t.scale_factors, sizeof out->biased_scale_factors);
+  out->transient_threshold = 1.0;
+  out->fixed_block_modes[0] = out->fixed_block_modes[1] = out->fixed_block_modes[2] = -1;
+  return C1_OK;
+}
+
+int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
+  if (!out) return fail(C1_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(C1_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= n) return fail(C1_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  c1_ctx *ctx = new c1_ctx();
+  ctx->device = device;
+  if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+  else {
+    const hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete ctx; return fail(C1_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    ctx->own_stream = true;
+  }
+  c1_tables t;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    if (g_tables_custom) t = g_tables; else default_tables(&t);
+  }
+  C1DevTables *h = new C1DevTables();
+  build_device_tables(t, h);
+  hipError_t me = hipMalloc(&ctx->d_tables, sizeof(C1DevTables));
+  if (me == hipSuccess) me = hipMalloc(&ctx->d_opts, sizeof(C1DevEncOpts));
+  if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
+  delete h;
+  if (me != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "table upload: %s", hipGetErrorString(me)); }
+  const char *env = getenv("C1_CHUNK_FRAMES");
+  ctx->chunk_frames = env ? atoll(env) : 32768;
+  if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
+  *out = ctx;
+  return C1_OK;
+}
+
+int c1_ctx_destroy(c1_ctx *ctx) {
+  if (!ctx) return C1_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  for (auto &t : ctx->timings) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+  for (auto e : ctx->event_pool) hipEventDestroy(e);
+  if (ctx->d_tables) hipFree(ctx->d_tables);
+  if (ctx->d_opts) hipFree(ctx->d_opts);
+  if (ctx->d_coefs) hipFree(ctx->d_coefs);
+  if (ctx->d_side) hipFree(ctx->d_side);
+  if (ctx->d_alloc) hipFree(ctx->d_alloc);
+  if (ctx->d_io) hipFree(ctx->d_io);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return C1_OK;
+}
+
+int c1_ctx_synchronize(c1_ctx *ctx) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_ctx_set_profiling(c1_ctx *ctx, int enabled) {
+  if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
+  ctx->profiling = enabled != 0;
+  return C1_OK;
+}
+
+int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!name || !ms) return fail(C1_ERR_ARG, "name or ms is NULL");
+  if ((rc = collect_timings(ctx))) return rc;
+  double total = 0;
+  int count = 0;
+  for (int k = 0; k < K_KINDS; k++) {
+    if (!strcmp(name, kKindNames[k])) {
+      *ms = ctx->ms[k];
+      if (launches) *launches = ctx->launches[k];
+      return C1_OK;
+    }
+    total += ctx->ms[k];
+    count += ctx->launches[k];
+  }
+  if (!strcmp(name, "total")) {
+    *ms = total;
+    if (launches) *launches = count;
+    return C1_OK;
+  }
+  return fail(C1_ERR_ARG, "unknown kernel name '%s'", name);
+}
+
+int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                     const c1_encode_options *opts, uint8_t *units) {
+  if (!units && frames > 0) return fail(C1_ERR_ARG, "units is NULL");
+  return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, units, nullptr, nullptr, nullptr, nullptr);
+}
+
+int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                            const c1_encode_options *opts, float *bands, float *coefs, uint8_t *side,
+                            uint8_t *alloc) {
+  return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, nullptr, bands, coefs, side, alloc);
+}
+
+int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                    const c1_encode_options *opts, uint8_t *units) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
+  if (frames == 0) return C1_OK;
+  if (!pcm || !units) return fail(C1_ERR_ARG, "pcm or units is NULL");
+  const size_t ch_bytes = (size_t)(frames + halo_frames) * 512 * sizeof(float);
+  const size_t unit_bytes = (size_t)frames * channels * C1_UNIT_BYTES;
+  const size_t unit_off = (ch_bytes * channels + 255) & ~(size_t)255;
+  if ((rc = ensure_io(ctx, unit_off + unit_bytes))) return rc;
+  const float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+  for (int c = 0; c < channels; c++) {
+    if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    float *d = reinterpret_cast<float *>((char *)ctx->d_io + ch_bytes * c);
+    HIP_TRY(hipMemcpyAsync(d, pcm[c] - (size_t)halo_frames * 512, ch_bytes, hipMemcpyHostToDevice, ctx->stream));
+    dptr[c] = d + (size_t)halo_frames * 512;
+  }
+  uint8_t *d_units = (uint8_t *)ctx->d_io + unit_off;
+  if ((rc = c1_encode_device(ctx, dptr, channels, frames, halo_frames, opts, d_units))) return rc;
+  HIP_TRY(hipMemcpyAsync(units, d_units, unit_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_decode_device(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int halo_units,
+                     float *const *pcm) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
+  if (halo_units < 0 || halo_units > 1) return fail(C1_ERR_ARG, "halo_units must be 0 or 1");
+  if (ctx->profiling) reset_timings(ctx);
+  if (frames == 0) return C1_OK;
+  if (!units || !pcm) return fail(C1_ERR_ARG, "units or pcm is NULL");
+  if ((uintptr_t)units & 3) return fail(C1_ERR_ARG, "units must be 4-byte aligned on the device");
+  C1DecodeLaunch L;
+  memset(&L, 0, sizeof L);
+  L.units = units;
+  L.channels = channels;
+  L.frames = frames;
+  L.halo_units = halo_units;
+  L.tables = ctx->d_tables;
+  for (int c = 0; c < channels; c++) {
+    if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    if ((uintptr_t)pcm[c] & 15) return fail(C1_ERR_ARG, "pcm[%d] must be 16-byte aligned on the device", c);
+    L.pcm[c] = pcm[c];
+  }
+  { ScopedTiming t(ctx, K_DECODE); c1k_launch_decode(L, ctx->stream); }
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int halo_units,
+                    float *const *pcm) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0 || halo_units < 0 || halo_units > 1) return fail(C1_ERR_ARG, "bad frames / halo_units");
+  if (frames == 0) return C1_OK;
+  if (!units || !pcm) return fail(C1_ERR_ARG, "units or pcm is NULL");
+  const size_t halo_bytes = (size_t)halo_units * channels * C1_UNIT_BYTES;   // multiple of 4
+  const size_t unit_bytes = (size_t)frames * channels * C1_UNIT_BYTES + halo_bytes;
+  const size_t pcm_off = (unit_bytes + 255) & ~(size_t)255;
+  const size_t ch_bytes = (size_t)frames * 512 * sizeof(float);
+  if ((rc = ensure_io(ctx, pcm_off + ch_bytes * channels))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->d_io, units - halo_bytes, unit_bytes, hipMemcpyHostToDevice, ctx->stream));
+  float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+  for (int c = 0; c < channels; c++) dptr[c] = reinterpret_cast<float *>((char *)ctx->d_io + pcm_off + ch_bytes * c);
+  if ((rc = c1_decode_device(ctx, (const uint8_t *)ctx->d_io + halo_bytes, channels, frames, halo_units, dptr))) return rc;
+  for (int c = 0; c < channels; c++) {
+    if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    HIP_TRY(hipMemcpyAsync(pcm[c], dptr[c], ch_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+// ---- stateful streams -------------------------------------------------------------------------------
+struct c1_enc_stream {
+  c1_ctx *ctx;
+  int channels;
+  c1_encode_options opts;
+  float *d_hist;       // channels * 2 frames: the last 1024 PCM samples of each channel
+  float *d_buf = nullptr;
+  uint8_t *d_units = nullptr;
+  int64_t cap_frames = 0;
+};
+
+int c1_enc_stream_create(c1_ctx *ctx, int channels, const c1_encode_options *opts, c1_enc_stream **out) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!out || !opts) return fail(C1_ERR_ARG, "out or opts is NULL");
+  if ((rc = check_channels(channels))) return rc;
+  C1DevEncOpts probe;
+  if ((rc = build_encode_opts(*opts, &probe))) return rc;
+  c1_enc_stream *s = new c1_enc_stream();
+  s->ctx = ctx; s->channels = channels; s->opts = *opts; s->d_hist = nullptr;
+  const size_t hb = (size_t)channels * 1024 * sizeof(float);
+  hipError_t e = hipMalloc(&s->d_hist, hb);
+  if (e == hipSuccess) e = hipMemsetAsync(s->d_hist, 0, hb, ctx->stream);   // zero history == stream start
+  if (e != hipSuccess) { delete s; return fail(C1_ERR_HIP, "enc stream alloc: %s", hipGetErrorString(e)); }
+  *out = s;
+  return C1_OK;
+}
+
+int c1_enc_stream_push(c1_enc_stream *s, const float *const *pcm, int64_t frames, uint8_t *units) {
+  if (!s) return fail(C1_ERR_ARG, "stream is NULL");
+  c1_ctx *ctx = s->ctx;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
+  if (frames == 0) return C1_OK;
+  if (!pcm || !units) return fail(C1_ERR_ARG, "pcm or units is NULL");
+  if (frames > s->cap_frames) {
+    if (s->d_buf) { hipFree(s->d_buf); hipFree(s->d_units); }
+    s->d_buf = nullptr; s->d_units = nullptr; s->cap_frames = 0;
+    HIP_TRY(hipMalloc(&s->d_buf, (size_t)s->channels * (frames + 2) * 512 * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->d_units, (size_t)s->channels * frames * C1_UNIT_BYTES));
+    s->cap_frames = frames;
+  }
+  const size_t stride = (size_t)(s->cap_frames + 2) * 512;
+  const float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+  for (int c = 0; c < s->channels; c++) {
+    if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    float *d = s->d_buf + stride * c;
+    HIP_TRY(hipMemcpyAsync(d, s->d_hist + 1024 * c, 1024 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d + 1024, pcm[c], (size_t)frames * 512 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    dptr[c] = d + 1024;
+  }
+  if ((rc = c1_encode_device(ctx, dptr, s->channels, frames, 2, &s->opts, s->d_units))) return rc;
+  for (int c = 0; c < s->channels; c++)   // new history = the last two frames of [history | pushed]
+    HIP_TRY(hipMemcpyAsync(s->d_hist + 1024 * c, s->d_buf + stride * c + (size_t)frames * 512, 1024 * sizeof(float),
+                           hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(units, s->d_units, (size_t)s->channels * frames * C1_UNIT_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_enc_stream_destroy(c1_enc_stream *s) {
+  if (!s) return C1_OK;
+  hipSetDevice(s->ctx->device);
+  hipStreamSynchronize(s->ctx->stream);
+  if (s->d_hist) hipFree(s->d_hist);
+  if (s->d_buf) hipFree(s->d_buf);
+  if (s->d_units) hipFree(s->d_units);
+  delete s;
+  return C1_OK;
+}
+
+struct c1_dec_stream {
+  c1_ctx *ctx;
+  int channels;
+  bool have_prev = false;
+  uint8_t *d_prev = nullptr;   // channels units of the previous frame
+  uint8_t *d_units = nullptr;
+  float *d_pcm = nullptr;
+  int64_t cap_frames = 0;
+};
+
+int c1_dec_stream_create(c1_ctx *ctx, int channels, c1_dec_stream **out) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!out) return fail(C1_ERR_ARG, "out is NULL");
+  if ((rc = check_channels(channels))) return rc;
+  c1_dec_stream *s = new c1_dec_stream();
+  s->ctx = ctx; s->channels = channels;
+  const hipError_t e = hipMalloc(&s->d_prev, (size_t)channels * C1_UNIT_BYTES);
+  if (e != hipSuccess) { delete s; return fail(C1_ERR_HIP, "dec stream alloc: %s", hipGetErrorString(e)); }
+  *out = s;
+  return C1_OK;
+}
+
+int c1_dec_stream_push(c1_dec_stream *s, const uint8_t *units, int64_t frames, float *const *pcm) {
+  if (!s) return fail(C1_ERR_ARG, "stream is NULL");
+  c1_ctx *ctx = s->ctx;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
+  if (frames == 0) return C1_OK;
+  if (!units || !pcm) return fail(C1_ERR_ARG, "units or pcm is NULL");
+  const size_t ub = (size_t)s->channels * C1_UNIT_BYTES;
+  if (frames > s->cap_frames) {
+    if (s->d_units) { hipFree(s->d_units); hipFree(s->d_pcm); }
+    s->d_units = nullptr; s->d_pcm = nullptr; s->cap_frames = 0;
+    HIP_TRY(hipMalloc(&s->d_units, ub * (frames + 1)));
+    HIP_TRY(hipMalloc(&s->d_pcm, (size_t)s->channels * frames * 512 * sizeof(float)));
+    s->cap_frames = frames;
+  }
+  if (s->have_prev) HIP_TRY(hipMemcpyAsync(s->d_units, s->d_prev, ub, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(s->d_units + ub, units, ub * frames, hipMemcpyHostToDevice, ctx->stream));
+  float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+  for (int c = 0; c < s->channels; c++) dptr[c] = s->d_pcm + (size_t)c * s->cap_frames * 512;
+  if ((rc = c1_decode_device(ctx, s->d_units + ub, s->channels, frames, s->have_prev ? 1 : 0, dptr))) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_prev, s->d_units + ub * frames, ub, hipMemcpyDeviceToDevice, ctx->stream));
+  s->have_prev = true;
+  for (int c = 0; c < s->channels; c++) {
+    if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    HIP_TRY(hipMemcpyAsync(pcm[c], dptr[c], (size_t)frames * 512 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_dec_stream_destroy(c1_dec_stream *s) {
+  if (!s) return C1_OK;
+  hipSetDevice(s->ctx->device);
+  hipStreamSynchronize(s->ctx->stream);
+  if (s->d_prev) hipFree(s->d_prev);
+  if (s->d_units) hipFree(s->d_units);
+  if (s->d_pcm) hipFree(s->d_pcm);
+  delete s;
+  return C1_OK;
+}
+
+// ---- synthetic input ----------------------------------------------------------------------------------
+int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, float *pcm) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
+  if (frames == 0) return C1_OK;
+  if (!pcm || ((uintptr_t)pcm & 15)) return fail(C1_ERR_ARG, "pcm must be a 16-byte aligned device pointer");
+  if (seed == 0) return fail(C1_ERR_ARG, "xorshift32 seed must be non-zero");
+  std::vector<uint32_t> states;
+  if (signal == C1_SIGNAL_WHITE) {
+    // one draw per sample: state before frame f = T^(512 f) seed
+    const XsMatrix jump = xs_power(512);
+    states.resize((size_t)frames);
+    uint32_t s = seed;
+    for (int64_t f = 0; f < frames; f++) { states[(size_t)f] = s; s = jump.apply(s); }
+  } else if (signal == C1_SIGNAL_PINK_BURSTS) {
+    // 512-frame segments; per 8 frames the generator draws 8*512 + 256 values, so the PRNG state at the
+    // start of every segment is the exact continuation; the integrator restarts from 0 there
+    const int64_t segs = (frames + 511) / 512;
+    const XsMatrix jump = xs_power(64ull * (8 * 512 + 256));
+    states.resize((size_t)segs);
+    uint32_t s = seed;
+    for (int64_t k = 0; k < segs; k++) { states[(size_t)k] = s; s = jump.apply(s); }
+  } else {
+    return fail(C1_ERR_ARG, "unknown signal %d", signal);
+  }
+  uint32_t *d_states = nullptr;
+  HIP_TRY(hipMalloc(&d_states, states.size() * sizeof(uint32_t)));
+  hipError_t e = hipMemcpy(d_states, states.data(), states.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    if (signal == C1_SIGNAL_WHITE) c1k_launch_generate_white(d_states, frames, pcm, ctx->stream);
+    else c1k_launch_generate_pink(d_states, frames, pcm, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  hipFree(d_states);
+  if (e != hipSuccess) return fail(C1_ERR_HIP, "generate: %s", hipGetErrorString(e));
+  return C1_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// c1_internal.h -- shared between the HIP kernels (c1_kernels.hip) and the C-ABI host side
+// (c1_api.hip).  Not part of the public boundary (that is include/carta1_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/carta1_hip.h"
+
+// ---- device-resident tables (one copy per context, in HBM; hot entries live in L1/K$) -------
+struct C1DevTables {
+  double tap_e[24];          // (double)QMF_EVEN[j]   constants.js:94-107
+  double tap_o[24];          // (double)QMF_ODD[j]  == tap_e[23-j]
+  double window[32];         // WINDOW_SHORT
+  double mdct_fwd64[32];
+  double mdct_fwd256[128];
+  double mdct_fwd512[256];
+  double mdct_inv64[32];
+  double mdct_inv256[128];
+  double mdct_inv512[256];
+  double fft_tw[256][2];     // twiddle of butterfly k in a stage of half-stride h: [h-1+k]; fft.js:44-64
+  double scale_factors[64];
+  double norm[64 * 16];      // quantRange(wl)/SCALE_FACTORS[sfi]   quantization.js:42-44
+  double log1p10;
+  double pad_;
+};
+
+// ---- per-call encoder options in device form ---------------------------------------------------
+struct C1DevEncOpts {
+  double biased[64];         // pow(SCALE_FACTORS, bias) from the host
+  double threshold;
+  int32_t modes[3];          // fixed modes or -1
+  int32_t pad_;
+  uint16_t rank[64 * 16];    // rank (1..960) of the Float32 heap priority of (sfi, wl); 0 = unused
+};
+
+// ---- geometry ------------------------------------------------------------------------------------
+constexpr int kRunFrames = 16;   // consecutive frames of one channel processed by one wave
+constexpr int kSideBytes = 64;   // per unit: sfi[52], modes byte, pad
+constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallback flag
+
+struct C1EncodeLaunch {
+  const float *pcm[C1_MAX_CHANNELS];
+  int channels;
+  int64_t frames;
+  int halo_frames;
+  const C1DevTables *tables;
+  const C1DevEncOpts *opts;
+  float *coefs;      // frames*channels*512   (workspace or caller tap)
+  uint8_t *side;     // frames*channels*64
+  uint8_t *alloc;    // frames*channels*32
+  float *bands;      // optional tap (may be null)
+  uint8_t *units;    // frames*channels*212   (may be null for stage taps)
+};
+
+struct C1DecodeLaunch {
+  const uint8_t *units;
+  int channels;
+  int64_t frames;
+  int halo_units;
+  const C1DevTables *tables;
+  float *pcm[C1_MAX_CHANNELS];
+};
+
+// launchers (c1_kernels.hip); all asynchronous on `stream`
+void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);
+void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
+void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream);
+void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
+void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream);
+void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream);

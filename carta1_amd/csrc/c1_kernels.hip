@@ -1,0 +1,1023 @@
+// c1_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ATRAC1 hot path.
+//
+// Numeric model (the reference is ECMAScript): every operation is an IEEE-754
+// double operation, no a*b+c fusion, and every Float32Array store rounds to binary32.  This file
+// is compiled with -ffp-contract=off; the ONLY fused operations are the QMF convolution terms,
+// where both factors are binary32 values so the double product is exact and fma(a,b,acc) equals
+// round(a*b)+acc bit for bit.  No MFMA: nothing here is a dense contraction.
+//
+// Work decomposition (one wavefront == one 64-thread workgroup, so __syncthreads() is a wave fence)
+//   k_analysis  one wave walks kRunFrames consecutive frames of one channel, carrying the QMF delay
+//               lines / MDCT overlap / transient history in LDS exactly like the reference's
+//               BufferPool (codec/core/buffers.js), after a 1-2 frame warm-up from the PCM halo.
+//               -> MDCT coefficients, scale-factor indices, block modes
+//   k_allocate  one LANE per (frame, candidate BFU count): the 8 greedy heaps of
+//               allocateBits (codec/coding/bitallocation.js:74-142) run side by side, 8 frames per wave
+//   k_pack      one wave per sound unit: quantize (quantization.js:34-56) + MSB-first bit packing
+//               (serialization.js:41-98) into the 212-byte unit
+//   k_decode    one wave walks kRunFrames consecutive units of one channel:
+//               unpack, dequantize, IMDCT + overlap-add, QMF synthesis
+#include "c1_internal.h"
+
+#pragma clang fp contract(off)
+
+#define C1_WAVE 64
+
+// The tables are written once per context before any kernel runs and never by a kernel: view them
+// through the constant address space so wave-uniform reads become scalar loads (SGPR operands).
+typedef const __attribute__((address_space(4))) C1DevTables *TablesPtr;
+#define C1_TABLES(p) ((TablesPtr)(p))
+// Re-derive the table pointer through an opaque asm once per frame: table reads then cannot be
+// hoisted out of the frame loop (hundreds of loop-invariant twiddles would spill the register file).
+// Same trick for the lane id: every LDS index of the (fully unrolled) frame body is a function of it,
+// and hoisting those out of the frame loop costs more registers than recomputing them.
+__device__ __forceinline__ int lane_for_this_frame(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+__device__ __forceinline__ TablesPtr tables_for_this_frame(const C1DevTables *p) {
+  unsigned long long v = (unsigned long long)p;
+  asm volatile("" : "+s"(v));
+  return (TablesPtr)v;
+}
+
+namespace {
+
+// ---- format tables: codec/core/constants.js:29-52, :141-143 -----------------------------------
+__constant__ uint8_t kSpecs[52] = {8, 8, 8, 8, 4,  4,  4,  4,  8,  8,  8,  8,  6,  6,  6,  6,  6,  6,
+                                   6, 6, 6, 6, 6,  6,  7,  7,  7,  7,  9,  9,  9,  9,  10, 10, 10, 10,
+                                   12, 12, 12, 12, 12, 12, 12, 12, 20, 20, 20, 20, 20, 20, 20, 20};
+__constant__ uint16_t kStartLong[52] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,
+                                        86,  92,  98,  104, 110, 116, 122, 128, 134, 140, 146, 152, 159,
+                                        166, 173, 180, 189, 198, 207, 216, 226, 236, 246, 256, 268, 280,
+                                        292, 304, 316, 328, 340, 352, 372, 392, 412, 432, 452, 472, 492};
+__constant__ uint16_t kStartShort[52] = {0,   32,  64,  96,  8,   40,  72,  104, 12,  44,  76,  108, 20,
+                                         52,  84,  116, 26,  58,  90,  122, 128, 160, 192, 224, 134, 166,
+                                         198, 230, 141, 173, 205, 237, 150, 182, 214, 246, 256, 288, 320,
+                                         352, 384, 416, 448, 480, 268, 300, 332, 364, 396, 428, 460, 492};
+// first coefficient slot (BFU-major order) of each BFU = prefix sum of kSpecs
+__constant__ uint16_t kBfuFirst[53] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,  86,
+                                       92,  98,  104, 110, 116, 122, 128, 134, 140, 146, 152, 159, 166, 173,
+                                       180, 189, 198, 207, 216, 226, 236, 246, 256, 268, 280, 292, 304, 316,
+                                       328, 340, 352, 372, 392, 412, 432, 452, 472, 492, 512};
+__constant__ uint8_t kAmounts[8] = {20, 28, 32, 36, 40, 44, 48, 52};
+
+__device__ __forceinline__ int wl_bits(int wl) { return wl == 0 ? 0 : wl + 1; }  // WORD_LENGTH_BITS
+__device__ __forceinline__ int band_of_bfu(int b) { return b >= 36 ? 2 : (b >= 20 ? 1 : 0); }
+__device__ __forceinline__ int bfu_start(int b, int mode) { return mode == 0 ? kStartLong[b] : kStartShort[b]; }
+// BFU that owns coefficient slot p (BFU-major order); sizes are piecewise constant
+__device__ __forceinline__ int bfu_of_slot(int p) {
+  if (p < 32) return p >> 3;
+  if (p < 48) return 4 + ((p - 32) >> 2);
+  if (p < 80) return 8 + ((p - 48) >> 3);
+  if (p < 152) return 12 + (p - 80) / 6;
+  if (p < 180) return 24 + (p - 152) / 7;
+  if (p < 216) return 28 + (p - 180) / 9;
+  if (p < 256) return 32 + (p - 216) / 10;
+  if (p < 352) return 36 + (p - 256) / 12;
+  return 44 + (p - 352) / 20;
+}
+
+__device__ __forceinline__ float f32(double x) { return (float)x; }  // Float32Array store
+
+// index of double element e in a QMF work buffer: 2 pad doubles after every 32, so that the
+// 16-byte reads of a wave whose lanes are 32 or 64 bytes apart spread over all LDS banks
+__device__ __forceinline__ int pidx(int e) { return e + ((e >> 5) << 1); }
+
+// ---- QMF convolution core ------------------------------------------------------------------------
+// Analysis (qmf.js:33-47): output i needs work[2i .. 2i+47]:
+//   even = sum_j work[2i+47-2j]*EVEN[j],  odd = sum_j work[2i+46-2j]*ODD[j],  j ascending.
+// A lane owns D consecutive outputs i = D*lane+d, i.e. the 46+2D doubles from 2*D*lane, read
+// as 16-byte (even,odd) pairs u = 22+D .. 0; pair u feeds tap j = d+23-u of output d, so walking
+// u downwards adds the terms of every sum in the reference's order.
+template <int D>
+__device__ __forceinline__ void qmf_analysis_core(const double *w, int lane, TablesPtr T,
+                                                  double (&even)[D], double (&odd)[D]) {
+  const int base = 2 * D * lane;
+#pragma unroll
+  for (int d = 0; d < D; d++) even[d] = odd[d] = 0.0;
+#pragma unroll
+  for (int u = 22 + D; u >= 0; --u) {
+    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx(base + 2 * u)]);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const int j = d + 23 - u;
+      if (j >= 0 && j < 24) {
+        odd[d] = __builtin_fma(x.x, T->tap_e[23 - j], odd[d]);    // exact product: both factors are binary32
+        even[d] = __builtin_fma(x.y, T->tap_e[j], even[d]);
+      }
+    }
+  }
+}
+// Synthesis (qmf.js:89-102): out[2i+1] = sum_j work[2i+2j]*EVEN[j], out[2i] = sum_j work[2i+2j+1]*ODD[j].
+// Same window; pair u feeds tap j = u-d, walking u upwards.
+template <int D>
+__device__ __forceinline__ void qmf_synthesis_core(const double *w, int lane, TablesPtr T,
+                                                   double (&s0)[D], double (&s1)[D]) {
+  const int base = 2 * D * lane;
+#pragma unroll
+  for (int d = 0; d < D; d++) s0[d] = s1[d] = 0.0;
+#pragma unroll
+  for (int u = 0; u <= 22 + D; ++u) {
+    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx(base + 2 * u)]);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const int j = u - d;
+      if (j >= 0 && j < 24) {
+        s0[d] = __builtin_fma(x.x, T->tap_e[j], s0[d]);
+        s1[d] = __builtin_fma(x.y, T->tap_e[23 - j], s1[d]);
+      }
+    }
+  }
+}
+
+// ---- radix-2 DIT FFT stages over a buffer that holds several independent transforms --------------
+// fft.js:35-66.  `points` complex values in re/im (already bit-reversed per transform); transform
+// sizes are given by size_at(e).  One stage = points/2 butterflies spread over the wave; a butterfly
+// is skipped when its transform is already complete.  Float32 storage rounds after every stage.
+template <int POINTS, typename SizeAt>
+__device__ __forceinline__ void fft_stages(float *re, float *im, int lane, TablesPtr T, int max_size,
+                                           SizeAt size_at) {
+  for (int h = 1; h < max_size; h <<= 1) {
+#pragma unroll
+    for (int m = 0; m < POINTS / 128; m++) {
+      const int t = lane + 64 * m;
+      const int k = t & (h - 1);
+      const int e = ((t - k) << 1) + k;
+      const int o = e + h;
+      if (2 * h <= size_at(e)) {
+        const double tr = T->fft_tw[h - 1 + k][0], ti = T->fft_tw[h - 1 + k][1];
+        const double er = re[e], ei = im[e], orr = re[o], oi = im[o];
+        const double xr = orr * tr - oi * ti;
+        const double xi = orr * ti + oi * tr;
+        re[e] = f32(er + xr);
+        im[e] = f32(ei + xi);
+        re[o] = f32(er - xr);
+        im[o] = f32(ei - xi);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int bitrev(int k, int log2n) { return (int)(__brev((unsigned)k) >> (32 - log2n)); }
+
+// smallest i with m <= SCALE_FACTORS[i], clamped to [0,63]  == findScaleFactor, bitallocation.js:290-299
+__device__ __forceinline__ int scale_factor_index(float maxabs, TablesPtr T) {
+  if (!(maxabs > 0.0f)) return 0;
+  const double m = (double)maxabs;
+  if (m > 1.0) return 63;                        // SCALE_FACTORS[63] = 2^0
+  int e = (int)((__float_as_uint(maxabs) >> 23) & 0xff) - 127;  // floor(log2 m) for normal m
+  if (e < -21) return 0;                         // also covers denormals (field 0 -> e = -127)
+  int i = 3 * (e + 21);                          // SCALE_FACTORS[i] = 2^e <= m
+  // m in [2^e, 2^(e+1)): answer is i, i+1, i+2 or i+3
+  int r = i;
+  if (m > T->scale_factors[i]) r = i + 1;
+  if (i + 1 <= 63 && m > T->scale_factors[i + 1 > 63 ? 63 : i + 1]) r = i + 2;
+  if (i + 2 <= 63 && m > T->scale_factors[i + 2 > 63 ? 63 : i + 2]) r = i + 3;
+  return r > 63 ? 63 : r;
+}
+
+// =====================================================================================================
+// k_analysis
+// =====================================================================================================
+struct alignas(16) AnalysisLds {
+  // state carried from frame to frame == the encoder half of BufferPool (buffers.js:30-59)
+  double d1[46];        // stage-1 QMF delay line (as doubles of binary32 values)
+  double d2[46];        // stage-2 QMF delay line
+  alignas(16) float band[512];      // low128 | mid128 | high256 of the current frame (never windowed in place)
+  float hi[39 + 256];   // delayed high band (encoder.js:84-90)
+  float ovl[96];        // mdctOverlap, 3 x 32
+  float mag[2][256];    // transientDetection magnitudes, current / previous (ping-pong)
+  double sums[18];
+  alignas(4) uint8_t sfi[64];
+  // scratch with disjoint lifetimes inside one frame
+  union alignas(16) {
+    struct { alignas(16) double w1[592]; alignas(16) double w2[320]; } q;                               // QMF work buffers
+    struct { alignas(16) float in[1024]; float re[256]; float im[256]; alignas(16) float coef[512]; } m;  // MDCT
+    struct { float re[512]; float im[512]; double term[4][256]; } t;              // transient detection
+  } u;
+};
+
+// mode-dependent geometry of the 256 complex FFT points of one frame: band 0 -> [0,64), band 1 ->
+// [64,128), band 2 -> [128,256); a long band is one transform, a short band is 16-point blocks.
+struct FrameModes {
+  int m0, m1, m2;
+  __device__ __forceinline__ int mode_of_band(int b) const { return b == 0 ? m0 : (b == 1 ? m1 : m2); }
+  __device__ __forceinline__ int fft_size_at(int p) const {
+    const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+    return mode_of_band(b) != 0 ? 16 : (b == 2 ? 128 : 64);
+  }
+};
+
+template <bool DETECT>
+__global__ __launch_bounds__(C1_WAVE, 2) void k_analysis(C1EncodeLaunch L) {
+  __shared__ AnalysisLds S;
+  const C1DevEncOpts *O = L.opts;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  const int ch = blockIdx.x % L.channels;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFrames;
+  const float *__restrict__ pcm = L.pcm[ch];
+
+  // zero state == stream start (buffers.js:30-59)
+  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
+  for (int i = lane; i < 39; i += 64) S.hi[i] = 0.0f;
+  for (int i = lane; i < 96; i += 64) S.ovl[i] = 0.0f;
+  for (int i = lane; i < 512; i += 64) (&S.mag[0][0])[i] = 0.0f;
+  int cur = 0;                                           // which half of S.mag is "current"
+  double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;   // lane b < 3: features of the previous frame, band b
+  __syncthreads();
+
+  const int warm = DETECT ? 2 : 1;
+  const int64_t f_end = (f0 + kRunFrames < L.frames) ? f0 + kRunFrames : L.frames;
+  for (int64_t f = f0 - warm; f < f_end; ++f) {
+    if (f < -(int64_t)L.halo_frames) continue;   // before the stream start: all-zero frame leaves the zero state
+    const bool qmf_only = (f == f0 - 2);         // detect warm-up frame -2 only feeds the delay lines
+    const bool emit = (f >= f0);
+    TablesPtr T = tables_for_this_frame(L.tables);
+    lane = lane_for_this_frame(lane0);
+
+    // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
+    {
+      const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f * 512);
+      const float4 a = p4[lane], b = p4[64 + lane];
+      double *w1 = S.u.q.w1;
+      if (lane < 46) w1[pidx(lane)] = S.d1[lane];
+      const int e0 = 46 + 4 * lane;
+      w1[pidx(e0 + 0)] = (double)a.x; w1[pidx(e0 + 1)] = (double)a.y;
+      w1[pidx(e0 + 2)] = (double)a.z; w1[pidx(e0 + 3)] = (double)a.w;
+      w1[pidx(e0 + 256)] = (double)b.x; w1[pidx(e0 + 257)] = (double)b.y;
+      w1[pidx(e0 + 258)] = (double)b.z; w1[pidx(e0 + 259)] = (double)b.w;
+    }
+    __syncthreads();
+    {
+      double ev[4], od[4];
+      qmf_analysis_core<4>(S.u.q.w1, lane, T, ev, od);
+      double *w2 = S.u.q.w2;
+      if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q.w1[pidx(512 + lane)]; }
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const float lo = f32(ev[d] + od[d]);   // qmf.js:44-45
+        const float hi = f32(ev[d] - od[d]);
+        w2[pidx(46 + 4 * lane + d)] = (double)lo;
+        S.hi[39 + 4 * lane + d] = hi;
+      }
+    }
+    __syncthreads();
+    {
+      double ev[2], od[2];
+      qmf_analysis_core<2>(S.u.q.w2, lane, T, ev, od);
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        S.band[2 * lane + d] = f32(ev[d] + od[d]);
+        S.band[128 + 2 * lane + d] = f32(ev[d] - od[d]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) S.band[256 + lane + 64 * m] = S.hi[lane + 64 * m];
+      if (lane < 46) S.d2[lane] = S.u.q.w2[pidx(256 + lane)];
+    }
+    __syncthreads();
+    {
+      float keep = 0.0f;
+      if (lane < 39) keep = S.hi[256 + lane];
+      __syncthreads();
+      if (lane < 39) S.hi[lane] = keep;
+    }
+    if (qmf_only) { __syncthreads(); continue; }
+
+    if (emit && L.bands) {
+      float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
+      const float4 *src = reinterpret_cast<const float4 *>(S.band);
+      dst[lane] = src[lane];
+      dst[64 + lane] = src[64 + lane];
+    }
+
+    // ---------------- blockSelectorStage (encoder.js:111-152) ----------------
+    FrameModes M{O->modes[0], O->modes[1], O->modes[2]};
+    if (DETECT) {
+      float *re = S.u.t.re, *im = S.u.t.im;
+      float *mcur = S.mag[cur];
+      const float *mprev = S.mag[cur ^ 1];
+      // performFFT (transient.js:17-35): real input, three transforms 128 | 128 | 256 in one buffer
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int p = lane + 64 * m;
+        const int base = p < 128 ? 0 : (p < 256 ? 128 : 256);
+        const int lg = p < 256 ? 7 : 8;
+        re[base + bitrev(p - base, lg)] = S.band[p];
+        im[p] = 0.0f;
+      }
+      __syncthreads();
+      fft_stages<512>(re, im, lane, T, 256, [](int e) { return e < 256 ? 128 : 256; });
+      // magnitudes of the positive-frequency half (transient.js:29-32) + per-bin terms of the features
+      bool valid[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int g = lane + 64 * m;                        // mag index: band0 [0,64) band1 [64,128) band2 [128,256)
+        const int src = g < 64 ? g : (g < 128 ? 128 + (g - 64) : 256 + (g - 128));
+        const double r = re[src], i = im[src];
+        const float mg = f32(sqrt(r * r + i * i));
+        mcur[g] = mg;
+        const double cm = (double)mg, pm = (double)mprev[g];
+        const double diff = cm - pm;
+        valid[m] = cm > 1e-10;
+        S.u.t.term[0][g] = diff > 0 ? diff : 0.0;           // spectral flux terms (transient.js:96-106)
+        S.u.t.term[1][g] = cm * cm;                         // energy terms (exact product)
+        S.u.t.term[2][g] = valid[m] ? log(cm) : 0.0;        // flatness terms (transient.js:126-133)
+        S.u.t.term[3][g] = valid[m] ? cm : 0.0;
+      }
+      const int nv0 = __popcll(__ballot(valid[0])), nv1 = __popcll(__ballot(valid[1]));
+      const int nv2 = __popcll(__ballot(valid[2])) + __popcll(__ballot(valid[3]));
+      __syncthreads();
+      // the reference accumulates every feature sequentially in double, index ascending; keep that
+      // order: 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high})
+      if (lane < 18) {
+        const int b = lane / 6, kind = lane - 6 * b;
+        const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
+        const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
+        const int start = g0 + (kind == 5 ? n / 2 : 0);
+        const int len = kind >= 4 ? n / 2 : n;
+        const double *arr = S.u.t.term[which] + start;
+        double acc = 0.0;
+        for (int i = 0; i < len; i++) acc += arr[i];
+        S.sums[lane] = acc;
+      }
+      __syncthreads();
+      int mode = 0;
+      if (lane < 3) {
+        const double s_flux = S.sums[6 * lane + 0], s_e = S.sums[6 * lane + 1], s_log = S.sums[6 * lane + 2];
+        const double s_lin = S.sums[6 * lane + 3], s_lo = S.sums[6 * lane + 4], s_hi = S.sums[6 * lane + 5];
+        const int nv = lane == 0 ? nv0 : (lane == 1 ? nv1 : nv2);
+        double norm = sqrt(s_e);
+        if (!(norm != 0.0)) norm = 1e-6;                     // `Math.sqrt(e) || 1e-6`
+        const double flux = s_flux / norm;
+        double flat = 0.0;                                    // calculateSpectralFlatness :120-141
+        if (nv > 0) {
+          const double gm = exp(s_log / (double)nv), am = s_lin / (double)nv;
+          flat = am > 1e-10 ? gm / am : 0.0;
+        }
+        const double tot = s_lo + s_hi;                       // calculateHighFrequencyRatio :149-164
+        const double hf = tot > 0 ? s_hi / tot : 0.0;
+        const double ce = s_e > 1e-10 ? s_e : 1e-10;          // calculateEnergyChange :172-189
+        const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
+        const double db = 10.0 * log10(ce / pe);
+        const double e_change = db > 0 ? db : 0.0;
+        const double flat_c = sqrt(fabs(flat - prev_flat));   // calculateTransientScore :197-226
+        const double hf_c = log1p(fabs(hf - prev_hf) * 10.0) / T->log1p10;
+        const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
+        const double score = (flux + flat_c + hf_c + e_c) / 4.0;
+        mode = (score > O->threshold) ? (lane + 1 > 2 ? lane + 1 : 2) : 0;   // encoder.js:143
+        prev_flat = flat; prev_hf = hf; prev_e = s_e;
+      }
+      M.m0 = __shfl(mode, 0); M.m1 = __shfl(mode, 1); M.m2 = __shfl(mode, 2);
+      cur ^= 1;
+      __syncthreads();
+    }
+
+    // ---------------- mdctStage (encoder.js:170-349) ----------------
+    float *in = S.u.m.in, *re = S.u.m.re, *im = S.u.m.im, *coef = S.u.m.coef;
+    if (emit) {
+      // MDCT inputs of the three bands (long: zero | overlap | samples with windowed tail | zero,
+      // encoder.js:228-258; short: [overlap | windowed block] per 32-sample block, :269-307)
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        const int g = lane + 64 * m;
+        const int b = g < 256 ? 0 : (g < 512 ? 1 : 2);
+        const int l = g - (b == 0 ? 0 : (b == 1 ? 256 : 512));
+        const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+        float v = 0.0f;
+        if (M.mode_of_band(b) == 0) {
+          const int ws = b == 2 ? 112 : 48;
+          const int x = l - ws - 32;
+          if (l >= ws && l < ws + 32) v = S.ovl[32 * b + (l - ws)];
+          else if (x >= 0 && x < Sb - 32) v = S.band[off + x];
+          else if (x >= Sb - 32 && x < Sb) v = f32((double)S.band[off + x] * T->window[31 - (x - (Sb - 32))]);
+        } else {
+          const int q = l >> 6, pos = l & 63;
+          if (pos < 32) v = q == 0 ? S.ovl[32 * b + pos] : f32(T->window[pos] * (double)S.band[off + 32 * (q - 1) + pos]);
+          else v = f32((double)S.band[off + 32 * q + (pos - 32)] * T->window[31 - (pos - 32)]);
+        }
+        in[g] = v;
+      }
+      __syncthreads();
+    }
+    // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
+    for (int i = lane; i < 96; i += 64) {
+      const int b = i >> 5, k = i & 31;
+      const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+      S.ovl[i] = f32(T->window[k] * (double)S.band[off + Sb - 32 + k]);
+    }
+    if (!emit) { __syncthreads(); continue; }
+
+    // pre-twiddle (mdct.js:76-105) straight into bit-reversed order
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int p = lane + 64 * m;
+      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), ibase = b == 0 ? 0 : (b == 1 ? 256 : 512);
+      const bool lng = M.mode_of_band(b) == 0;
+      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
+      const int lg = lng ? (b == 2 ? 7 : 6) : 4;
+      const int q = lng ? 0 : ((p - cbase) >> 4);
+      const int k = (p - cbase) - q * nfft;
+      const float *x = in + ibase + q * 64;
+      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
+      const int n4 = nfft, n34 = 3 * nfft, i = 2 * k;
+      double r, mm;
+      if (i < n4) { r = (double)x[n34 - 1 - i] + (double)x[n34 + i]; mm = (double)x[n4 + i] - (double)x[n4 - 1 - i]; }
+      else { r = (double)x[n34 - 1 - i] - (double)x[i - n4]; mm = (double)x[n4 + i] + (double)x[5 * n4 - 1 - i]; }
+      const double c = tab[i], s = tab[i + 1];
+      const int dst = cbase + q * nfft + bitrev(k, lg);
+      re[dst] = f32(r * c + mm * s);
+      im[dst] = f32(mm * c - r * s);
+    }
+    __syncthreads();
+    fft_stages<256>(re, im, lane, T, 128, [&](int e) { return M.fft_size_at(e); });
+    // post-twiddle (mdct.js:110-119) + spectrum reversal of bands 1,2 (utils.js:42-48)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int p = lane + 64 * m;
+      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
+      const bool lng = M.mode_of_band(b) == 0;
+      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
+      const int q = lng ? 0 : ((p - cbase) >> 4);
+      const int i = (p - cbase) - q * nfft;
+      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
+      const int n2 = 2 * nfft;
+      const double c = tab[2 * i], s = tab[2 * i + 1], rr = re[p], ii = im[p];
+      const float o0 = f32(-rr * c - ii * s);
+      const float o1 = f32(-rr * s + ii * c);
+      const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
+      float *dst = coef + obase + q * 32;
+      if (b > 0) { dst[n2 - 1 - j0] = o0; dst[n2 - 1 - j1] = o1; }
+      else { dst[j0] = o0; dst[j1] = o1; }
+    }
+    __syncthreads();
+
+    // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+    const int64_t unit = f * L.channels + ch;
+    {
+      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+      const float4 *src = reinterpret_cast<const float4 *>(coef);
+      dst[lane] = src[lane];
+      dst[64 + lane] = src[64 + lane];
+    }
+    if (lane < 52) {
+      const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
+      const int n = kSpecs[lane];
+      float mx = 0.0f;
+      for (int j = 0; j < n; j++) {
+        const float a = fabsf(coef[start + j]);
+        if (a > mx) mx = a;
+      }
+      S.sfi[lane] = (uint8_t)scale_factor_index(mx, T);
+    } else {
+      S.sfi[lane] = lane == 52 ? (uint8_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0;
+    }
+    __syncthreads();
+    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================
+// k_allocate : allocateBits (bitallocation.js:74-142)
+// =====================================================================================================
+// Heap entry (one 32-bit word): rank(16) | sfi(6) | wl(4) | bfu(6).  `rank` orders the Float32 priorities
+// biasedSF[sfi]*DISTORTION_DELTA_FACTORS[wl]/WORD_LENGTH_DELTA_BITS[wl] (bitallocation.js:226-231,267-269)
+// exactly: equal priorities have equal rank, so the strict `>` comparisons of siftDown (:325-331) -- and
+// with them the tie order -- are reproduced.  Heaps live in LDS as heap[slot][thread]: conflict-free.
+constexpr int kAllocThreads = 256;
+
+__device__ __forceinline__ void heap_sift_down(uint32_t *heap, int i, int size, uint32_t v) {
+  // heap points at this thread's slot-0 word; slots are kAllocThreads words apart
+  const uint32_t pv = v >> 16;
+  for (;;) {
+    const int l = 2 * i + 1;
+    if (l >= size) break;
+    const uint32_t el = heap[l * kAllocThreads];
+    const uint32_t er = (l + 1 < size) ? heap[(l + 1) * kAllocThreads] : 0u;
+    const uint32_t pl = el >> 16, pr = er >> 16;
+    int pick;
+    uint32_t ev;
+    if (pl > pv) {
+      if (pr > pl) { pick = l + 1; ev = er; } else { pick = l; ev = el; }
+    } else if (pr > pv) { pick = l + 1; ev = er; }
+    else break;
+    heap[i * kAllocThreads] = ev;
+    i = pick;
+  }
+  heap[i * kAllocThreads] = v;
+}
+
+__global__ __launch_bounds__(kAllocThreads) void k_allocate(C1EncodeLaunch L) {
+  __shared__ uint32_t heap[52 * kAllocThreads];
+  __shared__ uint8_t sfi_s[32][64];
+  __shared__ float zero_s[32][52];
+  __shared__ uint16_t rank_s[64 * 16];
+  const C1DevEncOpts *O = L.opts;
+  const int tid = threadIdx.x;
+  const int fl = tid >> 3, cand = tid & 7;                // frame-local index, candidate index
+  const int64_t units_total = L.frames * L.channels;
+  const int64_t unit0 = (int64_t)blockIdx.x * 32;
+  const int64_t unit = unit0 + fl;
+  const bool live = unit < units_total;
+
+  for (int i = tid; i < 64 * 16; i += kAllocThreads) rank_s[i] = O->rank[i];
+  for (int i = tid; i < 32 * 16; i += kAllocThreads) {     // side info: 16 dwords per unit
+    const int64_t u = unit0 + (i >> 4);
+    reinterpret_cast<uint32_t *>(&sfi_s[0][0])[i] = u < units_total ? reinterpret_cast<const uint32_t *>(L.side + u * kSideBytes)[i & 15] : 0u;
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * 52; i += kAllocThreads) {     // zeroBitDistortions (Float32Array, bitallocation.js:76,87-89)
+    const int f = i / 52, b = i - 52 * f;
+    const int s = sfi_s[f][b];
+    zero_s[f][b] = s > 0 ? f32(O->biased[s] * 2.0 * (double)kSpecs[b]) : 0.0f;
+  }
+  __syncthreads();
+
+  const int n = kAmounts[cand];
+  int remaining = 212 * 8 - 40 - 10 * n;                   // bitallocation.js:97-100
+  uint32_t *hp = heap + tid;
+  uint64_t res0 = 0, res1 = 0, res2 = 0, res3 = 0;          // final word-length index of every BFU, 4 bits each
+  auto record = [&](int b, int wl) {
+    const uint64_t v = (uint64_t)wl << ((b & 15) * 4);
+    const int w = b >> 4;
+    res0 |= w == 0 ? v : 0; res1 |= w == 1 ? v : 0; res2 |= w == 2 ? v : 0; res3 |= w == 3 ? v : 0;
+  };
+  int hs = 0;
+  if (live) {
+    // distributeBitsRDO (bitallocation.js:203-281)
+    for (int b = 0; b < n; b++) {
+      const int s = sfi_s[fl][b];
+      if (s == 0) continue;
+      hp[hs * kAllocThreads] = ((uint32_t)rank_s[s * 16] << 16) | ((uint32_t)s << 10) | (uint32_t)b;
+      hs++;
+    }
+    for (int i = (hs >> 1) - 1; i >= 0; i--) heap_sift_down(hp, i, hs, hp[i * kAllocThreads]);
+    while (remaining > 0 && hs > 0) {
+      const uint32_t top = hp[0];
+      const int b = top & 63, wl = (top >> 6) & 15, s = (top >> 10) & 63;
+      const int cost = (wl == 0 ? 2 : 1) * (int)kSpecs[b];   // WORD_LENGTH_DELTA_BITS = [2,1,1,...]
+      if (cost > remaining) {                                // does not fit: dropped for good (:251-258)
+        record(b, wl);
+        hs--;
+        if (hs > 0) heap_sift_down(hp, 0, hs, hp[hs * kAllocThreads]);
+        continue;
+      }
+      remaining -= cost;
+      const int nxt = wl + 1;
+      if (nxt < 15) {
+        const uint32_t v = ((uint32_t)rank_s[s * 16 + nxt] << 16) | ((uint32_t)s << 10) | ((uint32_t)nxt << 6) | (uint32_t)b;
+        heap_sift_down(hp, 0, hs, v);
+      } else {
+        record(b, nxt);
+        hs--;
+        if (hs > 0) heap_sift_down(hp, 0, hs, hp[hs * kAllocThreads]);
+      }
+    }
+    for (int i = 0; i < hs; i++) {                           // BFUs still queued keep the length they reached
+      const uint32_t e = hp[i * kAllocThreads];
+      record(e & 63, (e >> 6) & 15);
+    }
+  }
+  // calculateTotalDistortion (bitallocation.js:157-190): sequential double sum, index ascending
+  double total = 0.0;
+  if (live) {
+#pragma unroll
+    for (int b = 0; b < 52; b++) {
+      const uint64_t word = b < 16 ? res0 : (b < 32 ? res1 : (b < 48 ? res2 : res3));
+      const int wl = (int)((word >> ((b & 15) * 4)) & 15);
+      if (b >= n || wl == 0) { total += (double)zero_s[fl][b]; continue; }
+      const int s = sfi_s[fl][b];
+      if (s == 0) continue;
+      const double ip2 = __hiloint2double((1023 - wl_bits(wl)) << 20, 0);   // INV_POWER_OF_TWO[bits] = 2^-bits
+      total += O->biased[s] * ip2 * (double)kSpecs[b];
+    }
+  }
+  // strict `<` over candidates in ascending order keeps the smallest count on ties (:116-129);
+  // NaN / +Inf never win (`x < Infinity` is false) -> fallback (:132-139)
+  const bool ok = live && (total < __builtin_huge_val());
+  double best = ok ? total : __builtin_huge_val();
+  int best_c = ok ? cand : 8;
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    const double ot = __shfl_xor(best, d);
+    const int oc = __shfl_xor(best_c, d);
+    if (ot < best || (ot == best && oc < best_c)) { best = ot; best_c = oc; }
+  }
+  if (live) {
+    uint64_t *dst = reinterpret_cast<uint64_t *>(L.alloc + unit * kAllocBytes);
+    if (best_c == cand) {
+      dst[0] = res0; dst[1] = res1; dst[2] = res2;
+      dst[3] = res3 | ((uint64_t)cand << 60);
+    } else if (best_c == 8 && cand == 0) {
+      dst[0] = 0; dst[1] = 0; dst[2] = 0;
+      dst[3] = 1ull << 59;                                   // fallback: 20 BFUs, all indices zero
+    }
+  }
+}
+
+// =====================================================================================================
+// k_pack : quantize (quantization.js:34-56) + serializeFrame (serialization.js:41-98)
+// =====================================================================================================
+// ECMAScript ToInt32 of a double (what `| 0` does): truncate, wrap modulo 2^32.
+__device__ __forceinline__ int32_t to_int32(double x) {
+  const double t = trunc(x);
+  if (fabs(t) < 2147483648.0) return (int32_t)t;
+  const uint64_t bits = (uint64_t)__double_as_longlong(t);
+  const int e = (int)((bits >> 52) & 0x7ff);
+  if (e == 0x7ff) return 0;                                  // NaN, +-Infinity -> 0
+  const int sh = e - 1075;                                   // value = mant * 2^sh, sh >= -21 here
+  const uint64_t mant = (bits & 0xfffffffffffffull) | (1ull << 52);
+  uint32_t low;
+  if (sh >= 32) low = 0u;
+  else if (sh >= 0) low = (uint32_t)(mant << sh);
+  else low = (uint32_t)(mant >> (-sh));
+  return (int32_t)((bits >> 63) ? (0u - low) : low);
+}
+
+__device__ __forceinline__ void put_bits_be(uint32_t *words, int pos, uint32_t v, int nbits) {
+  // MSB-first (bitstream.js:15-40); words are big-endian 32-bit groups, assembled with LDS atomics
+  const int w = pos >> 5, o = pos & 31;
+  if (o + nbits <= 32) atomicOr(&words[w], v << (32 - o - nbits));
+  else {
+    const int lo = o + nbits - 32;
+    atomicOr(&words[w], v >> lo);
+    atomicOr(&words[w + 1], v << (32 - lo));
+  }
+}
+
+__global__ __launch_bounds__(C1_WAVE) void k_pack(C1EncodeLaunch L) {
+  __shared__ uint32_t words[56];
+  __shared__ int bit_off[53];
+  __shared__ uint8_t wl_s[52], sfi_s[64];
+  TablesPtr T = C1_TABLES(L.tables);
+  const int lane = threadIdx.x;
+  const int64_t unit = blockIdx.x;
+  const uint64_t *al = reinterpret_cast<const uint64_t *>(L.alloc + unit * kAllocBytes);
+  const uint64_t a3 = al[3];
+  const bool fallback = (a3 >> 59) & 1;
+  const int amount = (int)(a3 >> 60) & 7;
+  const int n = kAmounts[amount];
+  if (lane < 16) reinterpret_cast<uint32_t *>(sfi_s)[lane] = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes)[lane];
+  if (lane < 56) words[lane] = 0;
+  int wl = 0;
+  if (lane < 52) {
+    const uint64_t word = al[lane >> 4];
+    wl = lane < n ? (int)((word >> ((lane & 15) * 4)) & 15) : 0;
+    wl_s[lane] = (uint8_t)wl;
+  }
+  __syncthreads();
+  const int modes = sfi_s[52];
+  const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
+  // bit offset of every BFU's mantissas: exclusive prefix sum of bits*size over the wave
+  int mybits = (lane < n) ? wl_bits(wl) * (int)kSpecs[lane < 52 ? lane : 0] : 0;
+  int scan = mybits;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(scan, d);
+    if (lane >= d) scan += o;
+  }
+  if (lane < 52) bit_off[lane] = 16 + 10 * n + scan - mybits;
+  // header and per-BFU indices (serialization.js:46-77)
+  if (lane == 0) {
+    const uint32_t header = ((uint32_t)(2 - m0) << 14) | ((uint32_t)(2 - m1) << 12) | ((uint32_t)(3 - m2) << 10) | ((uint32_t)amount << 5);
+    atomicOr(&words[0], (header & 0xffffu) << 16);
+  }
+  if (lane < n) {
+    put_bits_be(words, 16 + 4 * lane, (uint32_t)wl, 4);
+    put_bits_be(words, 16 + 4 * n + 6 * lane, fallback ? 0u : (uint32_t)sfi_s[lane], 6);
+  }
+  __syncthreads();
+  // mantissas: coefficient slots in BFU-major order, 8 per lane
+  const float *coefs = L.coefs + (unit << 9);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const int p = lane + 64 * m;
+    const int b = bfu_of_slot(p);
+    if (b >= n) continue;
+    const int w = wl_s[b];
+    if (w == 0) continue;
+    const int bits = w + 1;
+    const int j = p - kBfuFirst[b];
+    const int s = fallback ? 0 : sfi_s[b];
+    int32_t y = 0;
+    if (s != 0) {
+      const int mode = b >= 36 ? m2 : (b >= 20 ? m1 : m0);
+      const double x = (double)coefs[bfu_start(b, mode) + j] * T->norm[s * 16 + w];
+      const int32_t range = (1 << (bits - 1)) - 1;
+      y = to_int32(x + (x >= 0 ? 0.5 : -0.5));                // round half away from zero, then `| 0`
+      y = y > range ? range : (y < -range ? -range : y);
+    }
+    put_bits_be(words, bit_off[b] + j * bits, (uint32_t)y & ((1u << bits) - 1u), bits);
+  }
+  __syncthreads();
+  if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(words[lane]);
+}
+
+// =====================================================================================================
+// k_decode : deserializeFrame + decode() closure (decoder.js:408-411)
+// =====================================================================================================
+struct alignas(16) DecodeLds {
+  double d1[46];        // stage-1 synthesis delay (qmfDelays.lowBand)
+  double d2[46];        // stage-2 synthesis delay (qmfDelays.midBand)
+  float dhi[39];        // high-band delay
+  float tail[48];       // last 16 IMDCT samples per band (imdctOverlap tails, decoder.js:227-230)
+  uint32_t words[56];   // the unit as big-endian words
+  int bit_off[53];
+  uint8_t wl[52], sfi[52];
+  float coef[512];
+  float band[512];
+  union alignas(16) {
+    struct { float re[256]; float im[256]; float mid[512]; } m;   // IMDCT
+    struct { alignas(16) double w2[320]; alignas(16) double w1[592]; float high[256]; } q;   // QMF synthesis
+  } u;
+};
+
+__device__ __forceinline__ uint32_t get_bits_be(const uint32_t *words, int pos, int nbits) {
+  // unpackBits (bitstream.js:49-70): stops at the end of the 212-byte buffer and returns what it has
+  const int avail = C1_UNIT_BYTES * 8 - pos;
+  if (avail <= 0 || nbits == 0) return 0u;
+  const int nb = nbits < avail ? nbits : avail;
+  const int w = pos >> 5, o = pos & 31;
+  const uint64_t two = ((uint64_t)words[w] << 32) | (uint64_t)words[w + 1];
+  return (uint32_t)((two >> (64 - o - nb)) & ((1ull << nb) - 1ull));
+}
+
+__global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
+  __shared__ DecodeLds S;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  const int ch = blockIdx.x % L.channels;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFrames;
+  float *__restrict__ pcm = L.pcm[ch];
+
+  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
+  for (int i = lane; i < 39; i += 64) S.dhi[i] = 0.0f;
+  for (int i = lane; i < 48; i += 64) S.tail[i] = 0.0f;
+  if (lane < 3) S.words[53 + lane] = 0u;
+  __syncthreads();
+
+  const int64_t f_end = (f0 + kRunFrames < L.frames) ? f0 + kRunFrames : L.frames;
+  for (int64_t f = f0 - 1; f < f_end; ++f) {
+    if (f < -(int64_t)L.halo_units) continue;
+    const bool emit = f >= f0;
+    const int64_t unit = f * L.channels + ch;
+    TablesPtr T = tables_for_this_frame(L.tables);
+    lane = lane_for_this_frame(lane0);
+
+    // ---------------- deserializeFrame (serialization.js:111-176) ----------------
+    if (lane < 53) S.words[lane] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane]);
+#pragma unroll
+    for (int m = 0; m < 8; m++) S.coef[lane + 64 * m] = 0.0f;
+    __syncthreads();
+    const uint32_t header = S.words[0] >> 16;
+    const int m0 = 2 - (int)((header >> 14) & 3), m1 = 2 - (int)((header >> 12) & 3), m2 = 3 - (int)((header >> 10) & 3);
+    const int n = kAmounts[(header >> 5) & 7];
+    int wl = 0;
+    if (lane < n) {
+      wl = (int)get_bits_be(S.words, 16 + 4 * lane, 4);
+      S.sfi[lane] = (uint8_t)get_bits_be(S.words, 16 + 4 * n + 6 * lane, 6);
+    }
+    if (lane < 52) S.wl[lane] = (uint8_t)wl;
+    const int mybits = (lane < n) ? wl_bits(wl) * (int)kSpecs[lane < 52 ? lane : 0] : 0;
+    int scan = mybits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(scan, d);
+      if (lane >= d) scan += o;
+    }
+    if (lane < 52) S.bit_off[lane] = 16 + 10 * n + scan - mybits;
+    __syncthreads();
+    // ---------------- dequantizationStage (decoder.js:52-98) ----------------
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int p = lane + 64 * m;
+      const int b = bfu_of_slot(p);
+      if (b >= n) continue;
+      const int w = S.wl[b];
+      if (w == 0) continue;
+      const int bits = w + 1, j = p - kBfuFirst[b];
+      const int s = S.sfi[b];
+      float v = 0.0f;
+      if (s != 0) {
+        const uint32_t raw = get_bits_be(S.words, S.bit_off[b] + j * bits, bits);
+        const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;   // bitstream.js:78-82
+        const int32_t range = (1 << (bits - 1)) - 1;
+        v = f32(((double)q * T->scale_factors[s]) / (double)range);                                   // quantization.js:74-76
+      }
+      const int mode = b >= 36 ? m2 : (b >= 20 ? m1 : m0);
+      S.coef[bfu_start(b, mode) + j] = v;
+    }
+    __syncthreads();
+
+    // ---------------- imdctStage (decoder.js:116-330) ----------------
+    FrameModes M{m0, m1, m2};
+    float *re = S.u.m.re, *im = S.u.m.im, *mid = S.u.m.mid;
+    // pre-twiddle (mdct.js:161-170), input un-reversed for bands 1,2
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int p = lane + 64 * m;
+      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
+      const bool lng = M.mode_of_band(b) == 0;
+      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
+      const int lg = lng ? (b == 2 ? 7 : 6) : 4;
+      const int q = lng ? 0 : ((p - cbase) >> 4);
+      const int i = (p - cbase) - q * nfft;
+      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_inv512 : T->mdct_inv256) : T->mdct_inv64;
+      const int n2 = 2 * nfft;
+      const float *x = S.coef + obase + q * 32;
+      const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
+      const double r = -(double)(b > 0 ? x[n2 - 1 - j0] : x[j0]);
+      const double mm = -(double)(b > 0 ? x[n2 - 1 - j1] : x[j1]);
+      const double c = tab[2 * i], s = tab[2 * i + 1];
+      const int dst = cbase + q * nfft + bitrev(i, lg);
+      re[dst] = f32(mm * s + r * c);
+      im[dst] = f32(mm * c - r * s);
+    }
+    __syncthreads();
+    fft_stages<256>(re, im, lane, T, 128, [&](int e) { return M.fft_size_at(e); });
+    // post-twiddle (mdct.js:177-208), keeping only the middle half the decoder uses (decoder.js:191-199)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int p = lane + 64 * m;
+      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
+      const bool lng = M.mode_of_band(b) == 0;
+      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
+      const int q = lng ? 0 : ((p - cbase) >> 4);
+      const int i = (p - cbase) - q * nfft;
+      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_inv512 : T->mdct_inv256) : T->mdct_inv64;
+      const int n2 = 2 * nfft, n4 = nfft;
+      const double c = tab[2 * i], s = tab[2 * i + 1], rr = re[p], ii = im[p];
+      const double r1 = rr * c + ii * s, i1 = rr * s - ii * c;
+      const int idx = (i < nfft / 2) ? 2 * i : (2 * (i - nfft / 2) + n4);
+      float *dst = mid + obase + q * 32;
+      dst[n2 - 1 - idx] = f32(r1);
+      dst[idx] = f32(i1);
+    }
+    __syncthreads();
+    // overlap-add (mdct.js:230-245 via decoder.js:203-232 long / :262-300 short)
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int g = lane + 64 * m;
+      const int b = g < 128 ? 0 : (g < 256 ? 1 : 2);
+      const int off = b == 0 ? 0 : (b == 1 ? 128 : 256), Sb = b == 2 ? 256 : 128;
+      const int l = g - off;
+      const bool lng = M.mode_of_band(b) == 0;
+      const int q = lng ? 0 : (l >> 5);            // block
+      const int k = lng ? l : (l & 31);            // position inside the block's output
+      float v;
+      if (k < 32) {
+        const float *prev = (q == 0) ? (S.tail + 16 * b) : (mid + off + 32 * (q - 1) + 16);
+        const float *curr = mid + off + 32 * q;
+        if (k < 16) {
+          const double w1 = T->window[k], w2 = T->window[31 - k];
+          v = f32((double)prev[k] * w2 - (double)curr[15 - k] * w1);
+        } else {
+          const int i = 31 - k;
+          const double w1 = T->window[i], w2 = T->window[31 - i];
+          v = f32((double)prev[i] * w1 + (double)curr[15 - i] * w2);
+        }
+      } else {
+        v = mid[off + k - 16];                     // long block only: invBuf[16 .. S-16)
+      }
+      S.band[g] = v;
+      (void)Sb;
+    }
+    __syncthreads();
+    if (lane < 48) {
+      const int b = lane >> 4, k = lane & 15;
+      const int off = b == 0 ? 0 : (b == 1 ? 128 : 256), Sb = b == 2 ? 256 : 128;
+      S.tail[lane] = mid[off + Sb - 16 + k];
+    }
+    __syncthreads();
+
+    // ---------------- qmfSynthesisStage (decoder.js:349-389) ----------------
+    double *w2 = S.u.q.w2, *w1 = S.u.q.w1;
+    float *high = S.u.q.high;
+    {
+      // high band delay compensation (:360-366)
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int i = lane + 64 * m;
+        high[i] = i < 39 ? S.dhi[i] : S.band[256 + i - 39];
+      }
+      float keep = 0.0f;
+      if (lane < 39) keep = S.band[256 + 217 + lane];
+      // stage 2: low + mid -> 256 samples (qmf.js:78-84 interleave)
+      if (lane < 46) w2[pidx(lane)] = S.d2[lane];
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const int i = 2 * lane + d;
+        const double l = S.band[i], h = S.band[128 + i];
+        w2[pidx(46 + 2 * i)] = (double)f32(0.5 * (l + h));
+        w2[pidx(46 + 2 * i + 1)] = (double)f32(0.5 * (l - h));
+      }
+      __syncthreads();
+      if (lane < 39) S.dhi[lane] = keep;
+    }
+    {
+      double s0[2], s1[2];
+      qmf_synthesis_core<2>(w2, lane, T, s0, s1);
+      if (lane < 46) { S.d2[lane] = w2[pidx(256 + lane)]; w1[pidx(lane)] = S.d1[lane]; }
+      // stage 1 input: (stage-2 output, delayed high); stage-2 output i pair: out[2i] = s1, out[2i+1] = s0
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const int i = 2 * lane + d;                       // stage-2 convolution index; produces samples 2i, 2i+1
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int sidx = 2 * i + t;                     // sample index in the 256-sample low band
+          const double l = (double)f32(t == 0 ? s1[d] : s0[d]);
+          const double h = high[sidx];
+          w1[pidx(46 + 2 * sidx)] = (double)f32(0.5 * (l + h));
+          w1[pidx(46 + 2 * sidx + 1)] = (double)f32(0.5 * (l - h));
+        }
+      }
+    }
+    __syncthreads();
+    {
+      double s0[4], s1[4];
+      qmf_synthesis_core<4>(w1, lane, T, s0, s1);
+      if (lane < 46) S.d1[lane] = w1[pidx(512 + lane)];
+      if (emit) {
+        float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512 + 8 * lane);
+        dst[0] = make_float4(f32(s1[0]), f32(s0[0]), f32(s1[1]), f32(s0[1]));
+        dst[1] = make_float4(f32(s1[2]), f32(s0[2]), f32(s1[3]), f32(s0[3]));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================
+// synthetic signals
+// =====================================================================================================
+__device__ __forceinline__ double xorshift_u(uint32_t &s) {
+  s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+  return ((double)s / 4294967296.0) * 2.0 - 1.0;
+}
+// one thread per frame; frame_states[f] = PRNG state before the frame's first sample
+__global__ void k_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= frames) return;
+  uint32_t s = frame_states[f];
+  float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512);
+  for (int i = 0; i < 128; i++) {
+    float4 v;
+    v.x = f32(xorshift_u(s) * 0.5); v.y = f32(xorshift_u(s) * 0.5);
+    v.z = f32(xorshift_u(s) * 0.5); v.w = f32(xorshift_u(s) * 0.5);
+    dst[i] = v;
+  }
+}
+// one thread per 512-frame segment: p = 0.98p + 0.05u, plus 0.8u' in the second half of frames 5 mod 8
+__global__ void k_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm) {
+  const int64_t seg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg * 512 >= frames) return;
+  uint32_t s = segment_states[seg];
+  const int64_t fend = (seg + 1) * 512 < frames ? (seg + 1) * 512 : frames;
+  double p = 0.0;
+  for (int64_t f = seg * 512; f < fend; f++) {
+    float *dst = pcm + f * 512;
+    const bool burst = (f & 7) == 5;
+    for (int i = 0; i < 512; i++) {
+      const double u = xorshift_u(s);
+      p = 0.98 * p + 0.05 * u;
+      double v = p;
+      if (burst && i >= 256) v += 0.8 * xorshift_u(s);
+      dst[i] = f32(v);
+    }
+  }
+}
+
+}  // namespace
+
+// ---- launchers -----------------------------------------------------------------------------------------
+void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream) {
+  const int64_t runs = (L.frames + kRunFrames - 1) / kRunFrames;
+  const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
+  if (detect) hipLaunchKernelGGL(k_analysis<true>, grid, block, 0, stream, L);
+  else hipLaunchKernelGGL(k_analysis<false>, grid, block, 0, stream, L);
+}
+void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
+  const int64_t units = L.frames * L.channels;
+  hipLaunchKernelGGL(k_allocate, dim3((unsigned)((units + 31) / 32)), dim3(kAllocThreads), 0, stream, L);
+}
+void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)(L.frames * L.channels)), dim3(C1_WAVE), 0, stream, L);
+}
+void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream) {
+  const int64_t runs = (L.frames + kRunFrames - 1) / kRunFrames;
+  hipLaunchKernelGGL(k_decode, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+}
+void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream) {
+  hipLaunchKernelGGL(k_generate_white, dim3((unsigned)((frames + 63) / 64)), dim3(64), 0, stream, frame_states, frames, pcm);
+}
+void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream) {
+  const int64_t segs = (frames + 511) / 512;
+  hipLaunchKernelGGL(k_generate_pink, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, stream, segment_states, frames, pcm);
+}

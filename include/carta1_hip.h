@@ -1,0 +1,156 @@
+/*
+ * carta1_hip.h -- C ABI of libcarta1_hip.so: the MI355X (gfx950) ATRAC1 hot path.
+ *
+ * This is the drop-in boundary for aynik/carta1's encode/decode hot path.  The
+ * reference has no FFI of its own; the seam is the module boundary between
+ * codec/pipeline/* + codec/io/processor.js (stay JavaScript) and
+ * codec/transforms/{qmf,mdct,fft}.js, codec/analysis/transient.js,
+ * codec/coding/{bitallocation,quantization}.js (replaced by HIP kernels).  Each
+ * entry point below names the reference code it stands in for (file:line in
+ * aynik/carta1 v1.1.10).  The N-API addon (carta1_amd/js/addon/) and the ctypes
+ * binding (carta1_amd/capi.py) bind exactly these symbols; INTEGRATION.md shows
+ * the reference-side patch.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; c1_last_error()
+ *    (thread-local) then holds the message.  There is NO CPU fallback: without a
+ *    usable HIP device every compute entry point fails with C1_ERR_NO_DEVICE.
+ *  - PCM is planar float32, one pointer per channel, 512 samples per frame.
+ *  - sound units are 212 bytes each, interleaved L,R,L,R,... for stereo
+ *    (codec/io/processor.js:125-130), unit index = frame * channels + channel.
+ *  - "history": a frame's unit depends on at most the 650 PCM samples before it
+ *    (266 with fixed block modes).  Batch calls take `halo_frames`
+ *    = how many whole frames (0..2) of real PCM sit in memory directly BEFORE the
+ *    pcm pointers; samples before that are taken as zero, which is exactly a
+ *    stream start (codec/core/buffers.js:30-42 zero-initialised BufferPool).
+ *  - decoded PCM of frame n depends on units n and n-1 only; decode calls take
+ *    `halo_units` (0 or 1) = whether the unit(s) of frame -1 precede the pointer.
+ */
+#ifndef CARTA1_HIP_H
+#define CARTA1_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C1_FRAME_SAMPLES 512
+#define C1_UNIT_BYTES 212
+#define C1_MAX_CHANNELS 2
+#define C1_ABI_VERSION 1
+
+enum {
+  C1_OK = 0,
+  C1_ERR_ARG = 1,        /* bad argument (message says which) */
+  C1_ERR_NO_DEVICE = 2,  /* no HIP device / runtime: the product path never falls back to CPU */
+  C1_ERR_HIP = 3,        /* a HIP call failed */
+  C1_ERR_STATE = 4       /* handle used in the wrong state */
+};
+
+/* Numeric tables the reference builds at module load with V8's Math.sin/cos/pow/sqrt
+ * (codec/core/constants.js:60-66,144-150; codec/transforms/mdct.js:27-36;
+ * codec/transforms/fft.js:37-39).  libm differs from V8 in the last bit on some entries,
+ * so the library never recomputes them: it carries the values the reference produced
+ * (c1_get_default_tables) and a JavaScript host may install the ones its own V8 computes
+ * (c1_set_tables) so results track the reference running in that same process. */
+typedef struct c1_tables {
+  double scale_factors[64];   /* SCALE_FACTORS            constants.js:144-150 */
+  double window_short[32];    /* WINDOW_SHORT             constants.js:60-66   */
+  double mdct_fwd64[32];      /* mdct64.sinCosTable       mdct.js:215          */
+  double mdct_fwd256[128];    /* mdct256.sinCosTable      mdct.js:216          */
+  double mdct_fwd512[256];    /* mdct512.sinCosTable      mdct.js:217          */
+  double mdct_inv64[32];      /* imdct64.sinCosTable      mdct.js:219          */
+  double mdct_inv256[128];    /* imdct256.sinCosTable     mdct.js:220          */
+  double mdct_inv512[256];    /* imdct512.sinCosTable     mdct.js:221          */
+  double fft_w[8][2];         /* (cos,sin)(-2*pi/stride), stride = 2..256; fft.js:37-39 */
+  double log1p_10;            /* Math.log1p(10)           transient.js:211     */
+} c1_tables;
+
+/* EncoderOptions as the hot path consumes them (codec/core/options.js:17-23). */
+typedef struct c1_encode_options {
+  double biased_scale_factors[64]; /* pow(SCALE_FACTORS[i], allocationBias), bitallocation.js:46-61;
+                                      computed by the HOST (its Math.pow), bias==1 -> SCALE_FACTORS */
+  double transient_threshold;      /* options.transientThresholdLow: the pipeline uses the LOW
+                                      threshold for all three bands (encoder.js:137-141) */
+  int32_t fixed_block_modes[3];    /* options.fixedBlockModes, or {-1,-1,-1} for transient detection */
+  int32_t reserved;
+} c1_encode_options;
+
+typedef struct c1_ctx c1_ctx; /* one per (device, stream): workspace + tables on that device */
+
+/* ---- library ------------------------------------------------------------------------- */
+int c1_abi_version(void);
+const char *c1_last_error(void);
+int c1_device_count(int *count);                 /* hipGetDeviceCount */
+int c1_get_default_tables(c1_tables *out);       /* the V8-produced defaults compiled into the library */
+int c1_set_tables(const c1_tables *tables);      /* NULL restores defaults; applies to contexts created afterwards */
+/* fills biased_scale_factors for allocationBias == 1 (exact copy, bitallocation.js:51-52) and sets
+ * threshold 1.0 / detection on: the EncoderOptions defaults (options.js:17-23) */
+int c1_default_encode_options(c1_encode_options *out);
+
+/* ---- contexts ------------------------------------------------------------------------- */
+int c1_ctx_create(int device, void *hip_stream /* hipStream_t or NULL = own stream */, c1_ctx **out);
+int c1_ctx_destroy(c1_ctx *ctx);
+int c1_ctx_synchronize(c1_ctx *ctx);
+/* milliseconds the device spent in the named kernel during the most recent *_device call on this
+ * context ("analysis", "allocate", "pack", "decode", or "total"), from HIP events on the context's
+ * stream; c1_ctx_set_profiling(ctx, 1) must have been set before the call */
+int c1_ctx_set_profiling(c1_ctx *ctx, int enabled);
+int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches);
+
+/* ---- encode: replaces the encode() frame closure body, encoder.js:438-450
+ *      (qmfAnalysisStage :57-96, blockSelectorStage :111-152, mdctStage :170-349,
+ *      quantizationStage :365-418) plus serializeFrame (serialization.js:41-98), batched ----- */
+
+/* device-resident: pcm[c] and units are DEVICE pointers; asynchronous on the context's stream */
+int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
+                     int halo_frames, const c1_encode_options *opts, uint8_t *units);
+/* host-resident: copies in, runs c1_encode_device, copies out, synchronises.
+ * This is what encodeAeaPcm's hot loop (processor.js:119-136) calls once per batch. */
+int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
+                    int halo_frames, const c1_encode_options *opts, uint8_t *units);
+
+/* ---- decode: replaces the decode() frame closure body, decoder.js:408-411
+ *      (dequantizationStage :52-98, imdctStage :116-330, qmfSynthesisStage :349-389)
+ *      plus deserializeFrame (serialization.js:111-176), batched ----------------------------- */
+int c1_decode_device(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames,
+                     int halo_units, float *const *pcm);
+int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames,
+                    int halo_units, float *const *pcm);
+
+/* ---- stateful streams: what one encode()/decode() closure + its BufferPool is
+ *      (encoder.js:438-441, buffers.js:7-81).  The stream keeps the PCM / unit history on the
+ *      device, so successive calls continue the same stream bit for bit. ---------------------- */
+typedef struct c1_enc_stream c1_enc_stream;
+typedef struct c1_dec_stream c1_dec_stream;
+int c1_enc_stream_create(c1_ctx *ctx, int channels, const c1_encode_options *opts, c1_enc_stream **out);
+int c1_enc_stream_push(c1_enc_stream *s, const float *const *pcm /* host */, int64_t frames,
+                       uint8_t *units /* host, frames*channels*212 */);
+int c1_enc_stream_destroy(c1_enc_stream *s);
+int c1_dec_stream_create(c1_ctx *ctx, int channels, c1_dec_stream **out);
+int c1_dec_stream_push(c1_dec_stream *s, const uint8_t *units /* host */, int64_t frames,
+                       float *const *pcm /* host */);
+int c1_dec_stream_destroy(c1_dec_stream *s);
+
+/* ---- device-resident synthetic input for measurement ------------- */
+enum { C1_SIGNAL_WHITE = 0, C1_SIGNAL_PINK_BURSTS = 1 };
+/* Fills pcm (DEVICE pointer, frames*512 floats) with a signal of the given statistics.  Every 512-
+ * frame segment restarts xorshift32 from a seed derived from (seed, segment), so segments are
+ * generated in parallel; segment 0 with seed s reproduces the first 512 frames of the generators
+ * in BASELINE.md section 4 exactly (the parity subset). */
+int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, float *pcm);
+
+/* ---- stage taps for bring-up and stage-level parity tests (device pointers) ---------------- */
+/* bands: frames*channels*512 floats (low128|mid128|high256 per unit index, before windowing);
+ * coefs: same shape (MDCT coefficients as quantizationStage receives them);
+ * side:  frames*channels*64 bytes: sfi[52], modes byte (m0|m1<<2|m2<<4);  any of the three may be NULL */
+int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
+                            int halo_frames, const c1_encode_options *opts, float *bands,
+                            float *coefs, uint8_t *side, uint8_t *alloc /* frames*channels*32 or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARTA1_HIP_H */

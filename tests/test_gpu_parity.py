@@ -1,0 +1,272 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's golden vectors and against the
+CPU oracle on the same seeded inputs.  Bit-exact on units (integer/byte work) and on decoded PCM."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+INDEX = json.load(open(os.path.join(G, 'kat_index.json')))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import carta1_amd as c1
+    c = c1.Context(0)
+    yield c
+    c.close()
+
+
+def make_input(case, frames):
+    n = frames * 512
+    if case['signal'] == 'white':
+        return [O.gen_white(1, n), O.gen_white(2, n)]
+    return [O.gen_pinkT(3, n), O.gen_pinkT(4, n)]
+
+
+def options_of(case):
+    import carta1_amd as c1
+    o = dict(case['options'])
+    bias = o.get('allocationBias', 1.0)
+    return c1.EncoderOptions(o, biased_table=O.biased_table(bias))
+
+
+def first_diff(a, b):
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    return bad[:8]
+
+
+def test_config1_known_answer(ctx):
+    import carta1_amd as c1
+    k = json.load(open(os.path.join(G, 'config1_sine1k.json')))
+    i = np.arange(512)
+    pcm = np.sin(2 * np.pi * 1000 * i / 44100).astype(np.float32)
+    units = ctx.encode([pcm], c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}))
+    assert units[0].tobytes().hex() == k['unit_hex']
+    f = c1.codec.deserialize_frame(units[0])
+    assert f['nBfu'] == 44 and f['wordLengthIndices'] == k['wordLengthIndices']
+    assert f['scaleFactorIndices'] == k['scaleFactorIndices']
+    assert f['quantizedCoefficients'] == k['quantizedCoefficients']
+    pcm_out = ctx.decode(units, 1)
+    assert sha(pcm_out[0]) == k['decoded_first_frame_sha256']
+
+
+@pytest.mark.parametrize('name', sorted(INDEX))
+def test_kat64_against_reference_fixtures(ctx, name):
+    case = INDEX[name]
+    chs = make_input(case, 64)
+    units = ctx.encode(chs, options_of(case))
+    ref_units = np.fromfile(os.path.join(G, 'kat64_%s.units.bin' % name), dtype=np.uint8).reshape(-1, 212)
+    assert first_diff(units, ref_units).size == 0, 'units differ at %s' % first_diff(units, ref_units)
+    assert sha(units) == case['units_sha256']
+    pcm = ctx.decode(ref_units, 2)
+    head = np.fromfile(os.path.join(G, 'kat64_%s.pcm8.bin' % name), dtype=np.float32)
+    assert np.array_equal(pcm[0][:4096].view(np.uint32), head[:4096].view(np.uint32))
+    assert np.array_equal(pcm[1][:4096].view(np.uint32), head[4096:].view(np.uint32))
+    assert sha(pcm[0]) == case['decoded_planar_L_sha256']
+    assert sha(pcm[1]) == case['decoded_planar_R_sha256']
+
+
+@pytest.mark.parametrize('name', sorted(INDEX))
+def test_long2048_against_reference_hashes(ctx, name):
+    case = INDEX[name]
+    lg = case['long2048']
+    chs = make_input(case, lg['frames'])
+    units = ctx.encode(chs, options_of(case))
+    modes = np.fromfile(os.path.join(G, 'long2048_%s.modes.bin' % name), dtype=np.uint8).astype(int)
+    hdr = units[:, 0].astype(int)
+    got = (2 - (hdr >> 6 & 3)) | ((2 - (hdr >> 4 & 3)) << 2) | ((3 - (hdr >> 2 & 3)) << 4)
+    assert np.array_equal(got, modes), 'block modes differ at units %s' % np.nonzero(got != modes)[0][:8]
+    assert sha(units) == lg['units_sha256']
+    pcm = ctx.decode(units, 2)
+    assert sha(pcm[0]) == lg['decoded_planar_L_sha256']
+    assert sha(pcm[1]) == lg['decoded_planar_R_sha256']
+
+
+def test_stage_taps_against_reference(ctx):
+    import torch
+    import carta1_amd as c1
+    pcm = O.gen_white(1, 3 * 512)
+    ref_bands = np.fromfile(os.path.join(G, 'stages_white1_bands.f32.bin'), dtype=np.float32)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    for tag, modes in (('m000', [0, 0, 0]), ('m223', [2, 2, 3])):
+        ref_coefs = np.fromfile(os.path.join(G, 'stages_white1_%s_coefs.f32.bin' % tag), dtype=np.float32)
+        ref_alloc = json.load(open(os.path.join(G, 'stages_white1_%s_alloc.json' % tag)))
+        bands = torch.zeros(3 * 512, dtype=torch.float32, device='cuda')
+        coefs = torch.zeros(3 * 512, dtype=torch.float32, device='cuda')
+        side = torch.zeros(3 * 64, dtype=torch.uint8, device='cuda')
+        alloc = torch.zeros(3 * 32, dtype=torch.uint8, device='cuda')
+        torch.cuda.synchronize()   # the context runs on its own stream
+        ctx.encode_stages_device([d_pcm.data_ptr()], 3, bands.data_ptr(), coefs.data_ptr(), side.data_ptr(),
+                                 alloc.data_ptr(), c1.EncoderOptions({'fixedBlockModes': modes}))
+        ctx.synchronize()
+        assert np.array_equal(bands.cpu().numpy().view(np.uint32), ref_bands.view(np.uint32))
+        assert np.array_equal(coefs.cpu().numpy().view(np.uint32), ref_coefs.view(np.uint32))
+        side_h = side.cpu().numpy().reshape(3, 64)
+        alloc_h = alloc.cpu().numpy().reshape(3, 32)
+        for f in range(3):
+            assert list(side_h[f, :52]) == ref_alloc[f]['sfi']
+            words = alloc_h[f].view(np.uint64)
+            n = c1.codec.BFU_AMOUNTS[int(words[3] >> np.uint64(60)) & 7]
+            wl = [int((int(words[b >> 4]) >> ((b & 15) * 4)) & 15) for b in range(n)]
+            assert n == ref_alloc[f]['nBfu'] and wl == ref_alloc[f]['wl']
+
+
+def _tonal(frames, seed):
+    # mixture of stationary sines + slow AM: the input class where float32 arithmetic flips 1 % of frames
+    rng = np.random.RandomState(seed)
+    t = np.arange(frames * 512, dtype=np.float64)
+    x = np.zeros_like(t)
+    for _ in range(6):
+        f, a, ph = rng.uniform(50, 18000), rng.uniform(0.02, 0.3), rng.uniform(0, 6.28)
+        x += a * np.sin(2 * np.pi * f * t / 44100 + ph) * (1 + 0.3 * np.sin(2 * np.pi * rng.uniform(0.1, 3) * t / 44100))
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize('modes,bias', [([0, 0, 0], 1.0), ([2, 2, 3], 1.0), ([0, 2, 0], 2.0), (None, 1.0), ([2, 0, 3], 0.5)])
+def test_tonal_stereo_against_oracle(ctx, modes, bias):
+    import carta1_amd as c1
+    frames = 3000
+    chs = [_tonal(frames, 5), _tonal(frames, 6)]
+    opt = {'allocationBias': bias}
+    if modes:
+        opt['fixedBlockModes'] = modes
+    want, _ = O.encode_stream(chs, fixed_modes=modes, bias=bias, threshold=1.0)
+    got = ctx.encode(chs, c1.EncoderOptions(opt, biased_table=O.biased_table(bias)))
+    assert first_diff(got, want).size == 0, 'units differ at %s' % first_diff(got, want)
+    pcm_want, _ = O.decode_stream(want, 2)
+    pcm_got = ctx.decode(want, 2)
+    for c in range(2):
+        assert np.array_equal(pcm_got[c].view(np.uint32), pcm_want[c].view(np.uint32))
+
+
+def test_halo_and_chunk_invariance(ctx):
+    """Encoding a slice of a stream with its PCM halo gives the same units as encoding the whole stream:
+    what frame-batch sharding across GPUs relies on."""
+    import carta1_amd as c1
+    frames = 400
+    for modes, halo in (([0, 0, 0], 1), ([2, 2, 3], 1), (None, 2)):
+        chs = [O.gen_pinkT(3, frames * 512), O.gen_pinkT(4, frames * 512)]
+        opt = c1.EncoderOptions({'fixedBlockModes': modes} if modes else {})
+        whole = ctx.encode(chs, opt).reshape(frames, 2, 212)
+        for a, b in ((0, 57), (57, 58), (58, 333), (333, 400)):
+            h = min(halo, a)
+            part = ctx.encode([c[(a - h) * 512:b * 512] for c in chs], opt, halo_frames=h).reshape(b - a, 2, 212)
+            assert np.array_equal(part, whole[a:b]), (modes, a, b)
+    # decode: one unit of history is enough
+    units = ctx.encode(chs, c1.EncoderOptions()).reshape(frames, 2, 212)
+    full = ctx.decode(units.reshape(-1, 212), 2)
+    for a, b in ((0, 33), (33, 34), (34, 400)):
+        h = min(1, a)
+        part = ctx.decode(units[a - h:b].reshape(-1, 212), 2, halo_units=h)
+        for c in range(2):
+            assert np.array_equal(part[c].view(np.uint32), full[c][a * 512:b * 512].view(np.uint32)), (a, b)
+
+
+def test_streams_continue_bit_for_bit(ctx):
+    import carta1_amd as c1
+    frames = 70
+    x = O.gen_pinkT(9, frames * 512)
+    opt = c1.EncoderOptions()
+    whole = ctx.encode([x], opt)
+    s = c1.EncoderStream(ctx, 1, opt)
+    parts = []
+    pos = 0
+    for n in (1, 1, 1, 5, 17, 1, 44):
+        parts.append(s.push([x[pos * 512:(pos + n) * 512]]))
+        pos += n
+    s.close()
+    assert np.array_equal(np.concatenate(parts), whole)
+    full = ctx.decode(whole, 1)[0]
+    d = c1.DecoderStream(ctx, 1)
+    outs, pos = [], 0
+    for n in (1, 2, 1, 30, 36):
+        outs.append(d.push(whole[pos:pos + n])[0])
+        pos += n
+    d.close()
+    assert np.array_equal(np.concatenate(outs).view(np.uint32), full.view(np.uint32))
+
+
+def test_decode_arbitrary_bytes_matches_oracle(ctx):
+    rng = np.random.RandomState(7)
+    units = rng.randint(0, 256, size=(600, 212)).astype(np.uint8)
+    want, _ = O.decode_stream(units, 2)
+    got = ctx.decode(units, 2)
+    for c in range(2):
+        assert np.array_equal(got[c].view(np.uint32), want[c].view(np.uint32))
+
+
+def test_edge_cases_against_reference(ctx):
+    import carta1_amd as c1
+    e = json.load(open(os.path.join(G, 'aea_edge_cases.json')))['cases']
+    units = c1.encode_pcm([O.gen_white(11, 700), O.gen_white(12, 700)], c1.EncoderOptions(), ctx)
+    assert units.tobytes().hex() == e['stereo700']['units_hex']
+    pcm = ctx.decode(units, 2)
+    assert [sha(pcm[0]), sha(pcm[1])] == e['stereo700']['decoded_sha256']
+    units = c1.encode_pcm([O.gen_white(13, 1300), O.gen_white(14, 600)], c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}), ctx)
+    assert sha(units) == e['ragged_1300_600']['units_sha256']
+    units = c1.encode_pcm([np.zeros(1024, np.float32)], c1.EncoderOptions(), ctx)
+    assert units.tobytes().hex() == e['silence_mono_2frames']['units_hex']
+    i = np.arange(2048)
+    loud = (4.0 * np.sin((2 * np.pi * 440 * i) / 44100)).astype(np.float32)
+    units = c1.encode_pcm([loud], c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}), ctx)
+    assert sha(units) == e['loud_sine_mono']['units_sha256']
+    assert sha(ctx.decode(units, 1)[0]) == e['loud_sine_mono']['decoded_sha256']
+    tiny = (O.gen_white(15, 1024).astype(np.float64) * 1e-36).astype(np.float32)
+    units = c1.encode_pcm([tiny], c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}), ctx)
+    assert units.tobytes().hex() == e['tiny_mono']['units_hex']
+    quiet = (O.gen_white(15, 1024).astype(np.float64) * 1e-6).astype(np.float32)
+    units = c1.encode_pcm([quiet], c1.EncoderOptions(), ctx)
+    assert sha(units) == e['quiet_mono']['units_sha256']
+    assert sha(ctx.decode(units, 1)[0]) == e['quiet_mono']['decoded_sha256']
+    # empty input
+    assert c1.encode_pcm([np.zeros(0, np.float32)], c1.EncoderOptions(), ctx).shape == (0, 212)
+    # huge and non-finite samples: the ToInt32 wrap path; must match the oracle exactly
+    wild = O.gen_white(21, 4 * 512).copy()
+    wild[100] = 3e9
+    wild[700] = -1e30
+    wild[1300] = 65504.0
+    want, _ = O.encode_stream([wild], fixed_modes=(0, 0, 0))
+    got = ctx.encode([wild], c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}))
+    assert np.array_equal(got, want)
+
+
+def test_aea_round_trip_api(ctx):
+    import carta1_amd as c1
+    l, r = O.gen_white(31, 700), O.gen_white(32, 700)
+    img = c1.encode_aea_pcm([l, r], {'title': 'x'}, ctx)
+    assert len(img) == 2048 + 4 * 212
+    info = c1.parse_aea_header(img[:2048])
+    assert info == {'title': 'x', 'frameCount': 4, 'channelCount': 2}
+    out = c1.decode_aea_pcm(img, ctx)
+    assert len(out) == 2 and len(out[0]) == 1024 and len(out[1]) == 1024   # processor.test.js:95-108
+    with pytest.raises(TypeError):
+        c1.encode_aea_pcm([l.astype(np.float64)], {}, ctx)
+    with pytest.raises(TypeError):
+        c1.decode_aea_pcm(12345, ctx)
+
+
+def test_device_generator_matches_host_generator(ctx):
+    import torch
+    import carta1_amd as c1
+    frames = 1100
+    buf = torch.zeros(frames * 512, dtype=torch.float32, device='cuda')
+    torch.cuda.synchronize()
+    ctx.generate_device(c1.SIGNAL_WHITE, 1, frames, buf.data_ptr())
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), O.gen_white(1, frames * 512).view(np.uint32))
+    ctx.generate_device(c1.SIGNAL_PINK_BURSTS, 3, frames, buf.data_ptr())
+    got = buf.cpu().numpy()
+    want = O.gen_pinkT(3, 512 * 512)
+    assert np.array_equal(got[:512 * 512].view(np.uint32), want.view(np.uint32))   # segment 0 == BASELINE generator
+    assert np.isfinite(got).all() and got[512 * 512:].std() > 0.01
