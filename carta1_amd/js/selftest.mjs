@@ -1,0 +1,124 @@
+// node selftest.mjs [--gpu]   -- used by tests/test_js_host.py
+// Without --gpu: host-side checks only (tables, serialization, options, addon loads and fails loudly).
+// With --gpu: encode/decode through the addon against the reference's golden vectors.
+import fs from 'fs'
+import path from 'path'
+import { fileURLToPath } from 'url'
+import * as c1 from './index.js'
+import { buildNativeTables } from './core/constants.js'
+import { native } from './native.js'
+
+const here = path.dirname(fileURLToPath(import.meta.url))
+const G = path.resolve(here, '../../tests/golden')
+const gpu = process.argv.includes('--gpu')
+let failed = 0
+const ok = (cond, what) => { if (!cond) { failed++; console.log('FAIL', what) } else console.log('ok  ', what) }
+const hex = (u8) => Buffer.from(u8.buffer, u8.byteOffset, u8.byteLength).toString('hex')
+const f64hex = (x) => { const b = Buffer.alloc(8); b.writeDoubleBE(x); return b.toString('hex') }
+
+function xorshift(seed) { let s = seed >>> 0; return () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return (s / 4294967296) * 2 - 1 } }
+function white(seed, n) { const r = xorshift(seed); const x = new Float32Array(n); for (let i = 0; i < n; i++) x[i] = Math.fround(r() * 0.5); return x }
+function pinkT(seed, n) { const r = xorshift(seed); const x = new Float32Array(n); let p = 0; for (let i = 0; i < n; i++) { const u = r(); p = 0.98 * p + 0.05 * u; let v = p; if ((i >> 9) % 8 === 5 && (i % 512) >= 256) v += 0.8 * r(); x[i] = v } return x }
+
+async function main() {
+  // tables computed by this V8 == the fixture (made by the reference under the generator's V8)
+  const t = JSON.parse(fs.readFileSync(path.join(G, 'tables.json')))
+  const mine = buildNativeTables()
+  const want = [].concat(t.scale_factors_f64, t.window_short_f64, t.mdct_sincos_f64.fwd64, t.mdct_sincos_f64.fwd256,
+    t.mdct_sincos_f64.fwd512, t.mdct_sincos_f64.inv64, t.mdct_sincos_f64.inv256, t.mdct_sincos_f64.inv512,
+    [2, 4, 8, 16, 32, 64, 128, 256].flatMap((s) => t.fft_w_f64[s]), [t.log1p_10_f64])
+  ok(mine.length === want.length && want.every((h, i) => f64hex(mine[i]) === h), 'host tables equal the reference tables bit for bit')
+  ok(Array.from(c1.BFU_START_LONG).join() === t.bfu_start_long.join() && Array.from(c1.SPECS_PER_BFU).join() === t.specs_per_bfu.join(), 'BFU layout tables')
+  for (const b of ['0.5', '2', '3.3']) {
+    const o = new c1.EncoderOptions({ allocationBias: Number(b) }).toNative()
+    ok(t.biased_scale_factors_f64[b].every((h, i) => f64hex(o[i]) === h), `biased scale factors, bias ${b}`)
+  }
+  // options behave like the reference's
+  let msg = ''
+  try { new c1.EncoderOptions({ allocationBias: 9 }) } catch (e) { msg = e.message }
+  ok(msg === 'Value for allocationBias must be between 0 and 5, got 9', 'option range error message')
+  const eo = new c1.EncoderOptions({ fixedBlockModes: [0, 2, 3], ignored: 1 })
+  ok(eo.fixedBlockModes.join() === '0,2,3' && eo.transientThresholdMid === 1.5 && eo.getValue('allocationBias') === 1, 'option accessors')
+  // sound unit <-> fields
+  const k = JSON.parse(fs.readFileSync(path.join(G, 'config1_sine1k.json')))
+  const unit = Uint8Array.from(Buffer.from(k.unit_hex, 'hex'))
+  const f = c1.deserializeFrame(unit)
+  ok(f.nBfu === 44 && Array.from(f.wordLengthIndices).join() === k.wordLengthIndices.join() &&
+     Array.from(f.scaleFactorIndices).join() === k.scaleFactorIndices.join() &&
+     f.quantizedCoefficients.every((q, i) => Array.from(q).join() === k.quantizedCoefficients[i].join()), 'deserializeFrame == reference fields')
+  ok(hex(c1.serializeFrame(f)) === k.unit_hex, 'serializeFrame round trip')
+  const kat = fs.readFileSync(path.join(G, 'kat64_pinkT_detect.units.bin'))
+  let same = true
+  for (let i = 0; i < 128; i++) { const u = Uint8Array.from(kat.subarray(i * 212, (i + 1) * 212)); if (hex(c1.serializeFrame(c1.deserializeFrame(u))) !== hex(u)) same = false }
+  ok(same, 'serialize(deserialize(u)) == u on 128 reference units')
+  const e = JSON.parse(fs.readFileSync(path.join(G, 'aea_edge_cases.json')))
+  ok(hex(c1.AeaFile.createHeader('encoded by carta1', 4, 2).subarray(0, 272)) === e.header_hex_first_272, 'AEA header bytes')
+  const info = c1.AeaFile.parseHeader(c1.AeaFile.createHeader('t', 7, 2))
+  ok(info.title === 't' && info.frameCount === 7 && info.channelCount === 2, 'AEA header parse')
+  msg = ''
+  try { c1.deserializeFrame(new Uint8Array(5)) } catch (err) { msg = err.message }
+  ok(msg === 'Frame must be 212 bytes', 'deserializeFrame length error')
+  let rejected = null
+  try { await c1.encodeAeaPcm([new Float64Array(4)]) } catch (err) { rejected = err }
+  ok(rejected instanceof TypeError && rejected.message === 'ATRAC1 encoding requires one or two Float32 channels', 'encodeAeaPcm TypeError')
+  rejected = null
+  try { await c1.decodeAeaPcm('nope') } catch (err) { rejected = err }
+  ok(rejected instanceof TypeError && rejected.message === 'ATRAC1 decoding requires AEA bytes or a Blob', 'decodeAeaPcm TypeError')
+  ok(native().abiVersion() === 1, 'addon loads')
+
+  if (!gpu) {
+    let err = null
+    try { await c1.encodeAeaPcm([new Float32Array(512)]) } catch (x) { err = x }
+    ok(err && /no HIP device|no ROCm/.test(err.message), 'no GPU -> the hot path throws (no CPU fallback): ' + (err && err.message))
+  } else {
+    // config 1 through the frame closure
+    const pcm = new Float32Array(512)
+    for (let i = 0; i < 512; i++) pcm[i] = Math.sin((2 * Math.PI * 1000 * i) / 44100)
+    const enc = c1.encode(new c1.EncoderOptions({ fixedBlockModes: [0, 0, 0] }))
+    const r = enc(pcm)
+    ok(hex(c1.serializeFrame(r)) === k.unit_hex && r.quantizedCoefficients.length === 44, 'encode() closure == config-1 known answer')
+    // 64-frame stereo known answers through encodeAeaPcm / decodeAeaPcm
+    const idx = JSON.parse(fs.readFileSync(path.join(G, 'kat_index.json')))
+    for (const name of Object.keys(idx)) {
+      const c = idx[name]
+      const n = 64 * 512
+      const chs = c.signal === 'white' ? [white(1, n), white(2, n)] : [pinkT(3, n), pinkT(4, n)]
+      const img = await c1.encodeAeaPcm(chs, Object.assign({ title: 'kat' }, c.options))
+      const ref = fs.readFileSync(path.join(G, `kat64_${name}.units.bin`))
+      const got = Buffer.from(img.buffer, img.byteOffset + 2048, img.length - 2048)
+      ok(got.equals(ref) && img.length === 2048 + 128 * 212, `encodeAeaPcm ${name}: units == reference`)
+      const pcmOut = await c1.decodeAeaPcm(img)
+      const head = fs.readFileSync(path.join(G, `kat64_${name}.pcm8.bin`))
+      const l8 = Buffer.from(pcmOut[0].buffer, pcmOut[0].byteOffset, 8 * 512 * 4)
+      const r8 = Buffer.from(pcmOut[1].buffer, pcmOut[1].byteOffset, 8 * 512 * 4)
+      ok(pcmOut.length === 2 && pcmOut[0].length === n && l8.equals(head.subarray(0, 16384)) && r8.equals(head.subarray(16384)), `decodeAeaPcm ${name}: PCM == reference`)
+    }
+    // frame closures continue a stream; decode() closure on frame fields
+    const x = pinkT(3, 8 * 512)
+    const e2 = c1.encode(new c1.EncoderOptions())
+    const d2 = c1.decode()
+    const ref = fs.readFileSync(path.join(G, 'kat64_pinkT_detect.units.bin'))
+    const refPcm = fs.readFileSync(path.join(G, 'kat64_pinkT_detect.pcm8.bin'))
+    let okUnits = true, okPcm = true
+    for (let fidx = 0; fidx < 8; fidx++) {
+      const fields = e2(x.subarray(fidx * 512, (fidx + 1) * 512).slice())
+      if (!Buffer.from(c1.serializeFrame(fields)).equals(ref.subarray(fidx * 2 * 212, fidx * 2 * 212 + 212))) okUnits = false
+      const out = d2(fields)
+      if (!Buffer.from(out.buffer, out.byteOffset, 2048).equals(refPcm.subarray(fidx * 2048, (fidx + 1) * 2048))) okPcm = false
+    }
+    ok(okUnits, 'encode() closure, 8 consecutive frames with detection == reference units')
+    ok(okPcm, 'decode() closure, 8 consecutive frames == reference PCM')
+    // 700-sample stereo (processor.test.js:95-108)
+    const img = await c1.encodeAeaPcm([white(11, 700), white(12, 700)])
+    ok(hex(img.subarray(2048)) === e.cases.stereo700.units_hex, 'ragged 700-sample stereo == reference')
+    const out = await c1.decodeAeaPcm(img)
+    ok(out.length === 2 && out[0].length === 1024 && out[1].length === 1024, 'decodeAeaPcm sizes')
+    // streams API
+    const frames = c1.AudioProcessor.frameBufferToFrames([white(11, 700), white(12, 700)])
+    const fieldsList = await c1.AudioProcessor.collectFrames(c1.AudioProcessor.encodeStream(frames, { channelCount: 2 }))
+    ok(fieldsList.length === 4 && hex(await c1.AudioProcessor.createAeaBytes(fieldsList, { title: 'encoded by carta1', channelCount: 2 })) === hex(img), 'AudioProcessor.encodeStream == encodeAeaPcm')
+  }
+  console.log(failed ? `${failed} FAILED` : 'ALL OK')
+  process.exit(failed ? 1 : 0)
+}
+main().catch((e) => { console.log('EXCEPTION', e); process.exit(2) })

@@ -3,7 +3,7 @@
  *
  * This is the drop-in boundary for aynik/carta1's encode/decode hot path.  The
  * reference has no FFI of its own; the seam is the module boundary between
- * codec/pipeline/* + codec/io/processor.js (stay JavaScript) and
+ * codec/pipeline/ and codec/io/processor.js (stay JavaScript) and
  * codec/transforms/{qmf,mdct,fft}.js, codec/analysis/transient.js,
  * codec/coding/{bitallocation,quantization}.js (replaced by HIP kernels).  Each
  * entry point below names the reference code it stands in for (file:line in
