@@ -485,20 +485,25 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis(C1EncodeLaunch L) {
 // =====================================================================================================
 // k_allocate : allocateBits (bitallocation.js:74-142)
 // =====================================================================================================
+// One LANE per greedy heap.  A 512-thread workgroup takes 64 sound units; wave w runs candidate BFU
+// count kAmounts[w] for all 64 of them (lane = unit), so the lanes of a wave do the same amount of work.
 // Heap entry (one 32-bit word): rank(16) | sfi(6) | wl(4) | bfu(6).  `rank` orders the Float32 priorities
 // biasedSF[sfi]*DISTORTION_DELTA_FACTORS[wl]/WORD_LENGTH_DELTA_BITS[wl] (bitallocation.js:226-231,267-269)
 // exactly: equal priorities have equal rank, so the strict `>` comparisons of siftDown (:325-331) -- and
-// with them the tie order -- are reproduced.  Heaps live in LDS as heap[slot][thread]: conflict-free.
-constexpr int kAllocThreads = 256;
+// with them the tie order -- are reproduced.  Heaps live in LDS as heap[slot][lane] (64 dwords per slot:
+// conflict-free, and the two children of a node are one ds_read2st64 apart); wave w owns kAmounts[w] slots.
+constexpr int kAllocThreads = 512;
+constexpr int kAllocUnits = 64;
+constexpr int kHeapSlots = 20 + 28 + 32 + 36 + 40 + 44 + 48 + 52;   // 300
 
 __device__ __forceinline__ void heap_sift_down(uint32_t *heap, int i, int size, uint32_t v) {
-  // heap points at this thread's slot-0 word; slots are kAllocThreads words apart
+  // heap points at this lane's slot-0 word; slots are 64 words apart
   const uint32_t pv = v >> 16;
   for (;;) {
     const int l = 2 * i + 1;
     if (l >= size) break;
-    const uint32_t el = heap[l * kAllocThreads];
-    const uint32_t er = (l + 1 < size) ? heap[(l + 1) * kAllocThreads] : 0u;
+    const uint32_t el = heap[l * 64];
+    const uint32_t er = (l + 1 < size) ? heap[(l + 1) * 64] : 0u;
     const uint32_t pl = el >> 16, pr = er >> 16;
     int pick;
     uint32_t ev;
@@ -506,41 +511,39 @@ __device__ __forceinline__ void heap_sift_down(uint32_t *heap, int i, int size, 
       if (pr > pl) { pick = l + 1; ev = er; } else { pick = l; ev = el; }
     } else if (pr > pv) { pick = l + 1; ev = er; }
     else break;
-    heap[i * kAllocThreads] = ev;
+    heap[i * 64] = ev;
     i = pick;
   }
-  heap[i * kAllocThreads] = v;
+  heap[i * 64] = v;
 }
 
-__global__ __launch_bounds__(kAllocThreads) void k_allocate(C1EncodeLaunch L) {
-  __shared__ uint32_t heap[52 * kAllocThreads];
-  __shared__ uint8_t sfi_s[32][64];
-  __shared__ float zero_s[32][52];
+__global__ __launch_bounds__(kAllocThreads, 4) void k_allocate(C1EncodeLaunch L) {
+  __shared__ uint32_t heap[kHeapSlots * 64];
   __shared__ uint16_t rank_s[64 * 16];
   const C1DevEncOpts *O = L.opts;
   const int tid = threadIdx.x;
-  const int fl = tid >> 3, cand = tid & 7;                // frame-local index, candidate index
+  const int lane = tid & 63, cand = tid >> 6;
   const int64_t units_total = L.frames * L.channels;
-  const int64_t unit0 = (int64_t)blockIdx.x * 32;
-  const int64_t unit = unit0 + fl;
+  const int64_t unit = (int64_t)blockIdx.x * kAllocUnits + lane;
   const bool live = unit < units_total;
 
   for (int i = tid; i < 64 * 16; i += kAllocThreads) rank_s[i] = O->rank[i];
-  for (int i = tid; i < 32 * 16; i += kAllocThreads) {     // side info: 16 dwords per unit
-    const int64_t u = unit0 + (i >> 4);
-    reinterpret_cast<uint32_t *>(&sfi_s[0][0])[i] = u < units_total ? reinterpret_cast<const uint32_t *>(L.side + u * kSideBytes)[i & 15] : 0u;
-  }
-  __syncthreads();
-  for (int i = tid; i < 32 * 52; i += kAllocThreads) {     // zeroBitDistortions (Float32Array, bitallocation.js:76,87-89)
-    const int f = i / 52, b = i - 52 * f;
-    const int s = sfi_s[f][b];
-    zero_s[f][b] = s > 0 ? f32(O->biased[s] * 2.0 * (double)kSpecs[b]) : 0.0f;
+  // the unit's 52 scale-factor indices stay in registers: 13 dwords of 4 bytes
+  uint32_t sf[13];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(L.side + (live ? unit : 0) * kSideBytes);
+    const uint4 a = src[0], b = src[1], c = src[2];
+    const uint32_t d = reinterpret_cast<const uint32_t *>(src)[12];
+    sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+    sf[8] = c.x; sf[9] = c.y; sf[10] = c.z; sf[11] = c.w; sf[12] = d;
   }
   __syncthreads();
 
   const int n = kAmounts[cand];
+  // first slot of wave w: 0,20,48,80,116,156,200,248
+  const int slot0 = cand == 0 ? 0 : cand == 1 ? 20 : cand == 2 ? 48 : cand == 3 ? 80 : cand == 4 ? 116 : cand == 5 ? 156 : cand == 6 ? 200 : 248;
+  uint32_t *hp = heap + slot0 * 64 + lane;
   int remaining = 212 * 8 - 40 - 10 * n;                   // bitallocation.js:97-100
-  uint32_t *hp = heap + tid;
   uint64_t res0 = 0, res1 = 0, res2 = 0, res3 = 0;          // final word-length index of every BFU, 4 bits each
   auto record = [&](int b, int wl) {
     const uint64_t v = (uint64_t)wl << ((b & 15) * 4);
@@ -549,37 +552,38 @@ __global__ __launch_bounds__(kAllocThreads) void k_allocate(C1EncodeLaunch L) {
   };
   int hs = 0;
   if (live) {
-    // distributeBitsRDO (bitallocation.js:203-281)
-    for (int b = 0; b < n; b++) {
-      const int s = sfi_s[fl][b];
-      if (s == 0) continue;
-      hp[hs * kAllocThreads] = ((uint32_t)rank_s[s * 16] << 16) | ((uint32_t)s << 10) | (uint32_t)b;
-      hs++;
+    // distributeBitsRDO (bitallocation.js:203-281): initial heap = BFUs with a non-zero scale factor
+#pragma unroll
+    for (int b = 0; b < 52; b++) {
+      const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+      if (b < n && s != 0) {
+        hp[hs * 64] = ((uint32_t)rank_s[s * 16] << 16) | ((uint32_t)s << 10) | (uint32_t)b;
+        hs++;
+      }
     }
-    for (int i = (hs >> 1) - 1; i >= 0; i--) heap_sift_down(hp, i, hs, hp[i * kAllocThreads]);
+    for (int i = (hs >> 1) - 1; i >= 0; i--) heap_sift_down(hp, i, hs, hp[i * 64]);
+    // greedy spending loop (:244-278), one sift per iteration: the root either gets its next priority
+    // or leaves the heap (does not fit :251-258, or reached the last word length :271-277)
     while (remaining > 0 && hs > 0) {
       const uint32_t top = hp[0];
       const int b = top & 63, wl = (top >> 6) & 15, s = (top >> 10) & 63;
-      const int cost = (wl == 0 ? 2 : 1) * (int)kSpecs[b];   // WORD_LENGTH_DELTA_BITS = [2,1,1,...]
-      if (cost > remaining) {                                // does not fit: dropped for good (:251-258)
-        record(b, wl);
-        hs--;
-        if (hs > 0) heap_sift_down(hp, 0, hs, hp[hs * kAllocThreads]);
-        continue;
-      }
-      remaining -= cost;
-      const int nxt = wl + 1;
-      if (nxt < 15) {
-        const uint32_t v = ((uint32_t)rank_s[s * 16 + nxt] << 16) | ((uint32_t)s << 10) | ((uint32_t)nxt << 6) | (uint32_t)b;
-        heap_sift_down(hp, 0, hs, v);
-      } else {
+      const int cost = (int)kSpecs[b] << (wl == 0 ? 1 : 0);   // WORD_LENGTH_DELTA_BITS = [2,1,1,...]
+      const bool fits = cost <= remaining;
+      remaining -= fits ? cost : 0;
+      const int nxt = wl + (fits ? 1 : 0);
+      const bool leaves = !fits || nxt >= 15;
+      uint32_t v;
+      if (leaves) {
         record(b, nxt);
         hs--;
-        if (hs > 0) heap_sift_down(hp, 0, hs, hp[hs * kAllocThreads]);
+        v = hp[hs * 64];
+      } else {
+        v = ((uint32_t)rank_s[s * 16 + nxt] << 16) | ((uint32_t)s << 10) | ((uint32_t)nxt << 6) | (uint32_t)b;
       }
+      if (hs > 0) heap_sift_down(hp, 0, hs, v);
     }
     for (int i = 0; i < hs; i++) {                           // BFUs still queued keep the length they reached
-      const uint32_t e = hp[i * kAllocThreads];
+      const uint32_t e = hp[i * 64];
       record(e & 63, (e >> 6) & 15);
     }
   }
@@ -588,27 +592,33 @@ __global__ __launch_bounds__(kAllocThreads) void k_allocate(C1EncodeLaunch L) {
   if (live) {
 #pragma unroll
     for (int b = 0; b < 52; b++) {
+      const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
       const uint64_t word = b < 16 ? res0 : (b < 32 ? res1 : (b < 48 ? res2 : res3));
       const int wl = (int)((word >> ((b & 15) * 4)) & 15);
-      if (b >= n || wl == 0) { total += (double)zero_s[fl][b]; continue; }
-      const int s = sfi_s[fl][b];
-      if (s == 0) continue;
-      const double ip2 = __hiloint2double((1023 - wl_bits(wl)) << 20, 0);   // INV_POWER_OF_TWO[bits] = 2^-bits
-      total += O->biased[s] * ip2 * (double)kSpecs[b];
+      const int size = kSpecs[b];
+      if (b >= n || wl == 0) {
+        // zeroBitDistortions[b] = Float32(biasedSF * 2 * size), 0 when sfi == 0 (:76,87-89)
+        total += s != 0 ? (double)f32(O->biased[s] * 2.0 * (double)size) : 0.0;
+      } else if (s != 0) {
+        const double ip2 = __hiloint2double((1023 - wl_bits(wl)) << 20, 0);   // INV_POWER_OF_TWO[bits] = 2^-bits
+        total += O->biased[s] * ip2 * (double)size;
+      }
     }
   }
-  // strict `<` over candidates in ascending order keeps the smallest count on ties (:116-129);
-  // NaN / +Inf never win (`x < Infinity` is false) -> fallback (:132-139)
-  const bool ok = live && (total < __builtin_huge_val());
-  double best = ok ? total : __builtin_huge_val();
-  int best_c = ok ? cand : 8;
-#pragma unroll
-  for (int d = 1; d < 8; d <<= 1) {
-    const double ot = __shfl_xor(best, d);
-    const int oc = __shfl_xor(best_c, d);
-    if (ot < best || (ot == best && oc < best_c)) { best = ot; best_c = oc; }
-  }
+  // pick the candidate: strict `<` in ascending candidate order keeps the smallest count on ties (:116-129);
+  // NaN / +Inf never win (`x < Infinity` is false) -> fallback (:132-139).  Totals go through the (now idle) heap LDS.
+  __syncthreads();
+  double *totals = reinterpret_cast<double *>(heap);
+  totals[cand * 64 + lane] = (live && total < __builtin_huge_val()) ? total : __builtin_huge_val();
+  __syncthreads();
   if (live) {
+    double best = __builtin_huge_val();
+    int best_c = 8;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const double t = totals[c * 64 + lane];
+      if (t < best) { best = t; best_c = c; }
+    }
     uint64_t *dst = reinterpret_cast<uint64_t *>(L.alloc + unit * kAllocBytes);
     if (best_c == cand) {
       dst[0] = res0; dst[1] = res1; dst[2] = res2;
@@ -1005,7 +1015,7 @@ void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t strea
 }
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
-  hipLaunchKernelGGL(k_allocate, dim3((unsigned)((units + 31) / 32)), dim3(kAllocThreads), 0, stream, L);
+  hipLaunchKernelGGL(k_allocate, dim3((unsigned)((units + kAllocUnits - 1) / kAllocUnits)), dim3(kAllocThreads), 0, stream, L);
 }
 void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack, dim3((unsigned)(L.frames * L.channels)), dim3(C1_WAVE), 0, stream, L);
