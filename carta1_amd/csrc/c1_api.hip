@@ -166,6 +166,8 @@ struct c1_ctx {
   float *d_coefs = nullptr;
   uint8_t *d_side = nullptr;
   uint8_t *d_alloc = nullptr;
+  uint8_t *d_cand = nullptr;
+  uint32_t *d_work = nullptr;      // [0] = count, list from [4]
   int64_t chunk_frames = 0;
   // profiling
   bool profiling = false;
@@ -188,11 +190,13 @@ int ctx_bind(c1_ctx *ctx) {
 
 int ensure_workspace(c1_ctx *ctx, int64_t units) {
   if (units <= ctx->ws_units) return C1_OK;
-  if (ctx->d_coefs) { hipFree(ctx->d_coefs); hipFree(ctx->d_side); hipFree(ctx->d_alloc); }
-  ctx->d_coefs = nullptr; ctx->d_side = nullptr; ctx->d_alloc = nullptr; ctx->ws_units = 0;
+  if (ctx->d_coefs) { hipFree(ctx->d_coefs); hipFree(ctx->d_side); hipFree(ctx->d_alloc); hipFree(ctx->d_cand); hipFree(ctx->d_work); }
+  ctx->d_coefs = nullptr; ctx->d_side = nullptr; ctx->d_alloc = nullptr; ctx->d_cand = nullptr; ctx->d_work = nullptr; ctx->ws_units = 0;
   HIP_TRY(hipMalloc(&ctx->d_coefs, (size_t)units * 512 * sizeof(float)));
   HIP_TRY(hipMalloc(&ctx->d_side, (size_t)units * kSideBytes));
   HIP_TRY(hipMalloc(&ctx->d_alloc, (size_t)units * kAllocBytes));
+  HIP_TRY(hipMalloc(&ctx->d_cand, (size_t)units * kCandidateBytes));
+  HIP_TRY(hipMalloc(&ctx->d_work, ((size_t)units * 7 + 4) * sizeof(uint32_t)));
   ctx->ws_units = units;
   return C1_OK;
 }
@@ -291,7 +295,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   const bool detect = opts->fixed_block_modes[0] < 0;
   const int64_t chunk = ctx->chunk_frames;
   const bool taps = coefs_tap || side_tap || alloc_tap;
-  if (!taps && (rc = ensure_workspace(ctx, std::min(frames, chunk) * channels))) return rc;
+  if ((rc = ensure_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (taps && (!coefs_tap || !side_tap || !alloc_tap)) return fail(C1_ERR_ARG, "coefs, side and alloc taps must be given together");
   for (int64_t f0 = 0; f0 < frames; f0 += taps ? frames : chunk) {
     const int64_t n = taps ? frames : std::min(chunk, frames - f0);
@@ -306,6 +310,9 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.coefs = taps ? coefs_tap : ctx->d_coefs;
     L.side = taps ? side_tap : ctx->d_side;
     L.alloc = taps ? alloc_tap : ctx->d_alloc;
+    L.cand = ctx->d_cand;
+    L.work_count = ctx->d_work;
+    L.work_list = ctx->d_work + 4;
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     { ScopedTiming t(ctx, K_ANALYSIS); c1k_launch_analysis(L, detect, ctx->stream); }
@@ -438,6 +445,8 @@ int c1_ctx_destroy(c1_ctx *ctx) {
   if (ctx->d_coefs) hipFree(ctx->d_coefs);
   if (ctx->d_side) hipFree(ctx->d_side);
   if (ctx->d_alloc) hipFree(ctx->d_alloc);
+  if (ctx->d_cand) hipFree(ctx->d_cand);
+  if (ctx->d_work) hipFree(ctx->d_work);
   if (ctx->d_io) hipFree(ctx->d_io);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

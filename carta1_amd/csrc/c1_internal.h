@@ -38,6 +38,7 @@ struct C1DevEncOpts {
 constexpr int kRunFrames = 16;   // consecutive frames of one channel processed by one wave
 constexpr int kSideBytes = 64;   // per unit: sfi[52], modes byte, pad
 constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallback flag
+constexpr int kCandidateBytes = 8 * 8 + 8 * 32;  // per unit: 8 totals + 8 results (bit allocation scratch)
 
 struct C1EncodeLaunch {
   const float *pcm[C1_MAX_CHANNELS];
@@ -49,6 +50,9 @@ struct C1EncodeLaunch {
   float *coefs;      // frames*channels*512   (workspace or caller tap)
   uint8_t *side;     // frames*channels*64
   uint8_t *alloc;    // frames*channels*32
+  uint8_t *cand;     // frames*channels*kCandBytes: per-candidate totals and results
+  uint32_t *work_list;   // frames*channels*7 entries (unit<<3 | candidate)
+  uint32_t *work_count;
   float *bands;      // optional tap (may be null)
   uint8_t *units;    // frames*channels*212   (may be null for stage taps)
 };
