@@ -315,7 +315,13 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.work_list = ctx->d_work + 4;
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
-    { ScopedTiming t(ctx, K_ANALYSIS); c1k_launch_analysis(L, detect, ctx->stream); }
+    const bool all_long = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&
+                          opts->fixed_block_modes[2] == 0 && !getenv("C1_NO_FAST_LONG");
+    {
+      ScopedTiming t(ctx, K_ANALYSIS);
+      if (all_long) c1k_launch_analysis_long(L, ctx->stream);
+      else c1k_launch_analysis(L, detect, ctx->stream);
+    }
     { ScopedTiming t(ctx, K_ALLOCATE); c1k_launch_allocate(L, ctx->stream); }
     if (L.units) { ScopedTiming t(ctx, K_PACK); c1k_launch_pack(L, ctx->stream); }
   }

@@ -36,6 +36,7 @@ struct C1DevEncOpts {
 
 // ---- geometry ------------------------------------------------------------------------------------
 constexpr int kRunFrames = 16;   // consecutive frames of one channel processed by one wave
+constexpr int kRunFramesLong = 32;   // same, in the all-long-blocks fast path
 constexpr int kSideBytes = 64;   // per unit: sfi[52], modes byte, pad
 constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallback flag
 constexpr int kCandidateBytes = 8 * 8 + 8 * 32;  // per unit: 8 totals + 8 results (bit allocation scratch)
@@ -68,6 +69,7 @@ struct C1DecodeLaunch {
 
 // launchers (c1_kernels.hip); all asynchronous on `stream`
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);
+void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0]
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);

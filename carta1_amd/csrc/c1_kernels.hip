@@ -485,6 +485,214 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis(C1EncodeLaunch L) {
 }
 
 // =====================================================================================================
+// k_analysis_long : the same stage chain specialised for fixed block modes [0,0,0] (all bands long)
+// =====================================================================================================
+// Every vector instruction costs the same 4 cycles here, so this path is shaped to minimise their count:
+// the MDCT inputs of the three bands live in LDS buffers whose zero regions are written once per wave,
+// the FFT works on interleaved (re,im) pairs with compile-time strides, and there is no per-element
+// mode logic.  Numerics are identical to k_analysis (same operations in the same order).
+struct alignas(16) LongLds {
+  double d1[46];                 // stage-1 QMF delay line
+  double d2[46];                 // stage-2 QMF delay line
+  alignas(16) float band[512];   // low128 | mid128 | high256, raw
+  alignas(16) float hbuf[296];   // delayed high band: [0,39) tail of the previous frame, [39,295) this frame
+  alignas(16) float in0[256];    // MDCT-256 input, low band:  0 x48 | overlap32 | samples128 | 0 x48
+  alignas(16) float in1[256];    // MDCT-256 input, mid band
+  alignas(16) float in2[512];    // MDCT-512 input, high band: 0 x112 | overlap32 | samples256 | 0 x112
+  alignas(4) uint8_t sfi[64];
+  union alignas(16) {
+    struct { alignas(16) double w1[592]; alignas(16) double w2[320]; } q;
+    struct { alignas(16) float2 z[256]; alignas(16) float coef[512]; } m;
+  } u;
+};
+
+// one radix-2 butterfly (fft.js:46-60) on interleaved points; H = half stride (compile time)
+template <int H>
+__device__ __forceinline__ void fft_butterfly(float2 *z, int t, TablesPtr T) {
+  const int k = t & (H - 1);
+  const int e = ((t - k) << 1) + k;
+  const double tr = T->fft_tw[H - 1 + k][0], ti = T->fft_tw[H - 1 + k][1];
+  const float2 ze = z[e], zo = z[e + H];
+  const double er = ze.x, ei = ze.y, orr = zo.x, oi = zo.y;
+  const double xr = orr * tr - oi * ti;
+  const double xi = orr * ti + oi * tr;
+  z[e] = make_float2(f32(er + xr), f32(ei + xi));
+  z[e + H] = make_float2(f32(er - xr), f32(ei - xi));
+}
+
+// pre-twiddle of complex point k of an N-point MDCT (mdct.js:76-105), N4 = N/4, written bit-reversed
+template <int N4, int LG>
+__device__ __forceinline__ void mdct_pre(const float *in, const __attribute__((address_space(4))) double *tab, int k,
+                                         float2 *z) {
+  const int i = 2 * k;
+  const bool lo = i < N4;
+  const float a = in[3 * N4 - 1 - i];
+  const float c = in[N4 + i];
+  const uint32_t sign = lo ? 0u : 0x80000000u;       // second half: r = a - b, m = c + d
+  const float b = __uint_as_float(__float_as_uint(in[lo ? 3 * N4 + i : i - N4]) ^ sign);
+  const float d = __uint_as_float(__float_as_uint(in[lo ? N4 - 1 - i : 5 * N4 - 1 - i]) ^ sign);
+  const double r = (double)a + (double)b;
+  const double mm = (double)c - (double)d;
+  const double cs = tab[i], sn = tab[i + 1];
+  z[bitrev(k, LG)] = make_float2(f32(r * cs + mm * sn), f32(mm * cs - r * sn));
+}
+
+// post-twiddle (mdct.js:110-119) of point i; REV = spectrum reversal of bands 1,2 (utils.js:42-48)
+template <int NFFT, bool REV>
+__device__ __forceinline__ void mdct_post(const float2 *z, const __attribute__((address_space(4))) double *tab, int i,
+                                          float *dst) {
+  const float2 zz = z[i];
+  const double cs = tab[2 * i], sn = tab[2 * i + 1], rr = zz.x, ii = zz.y;
+  const float o0 = f32(-rr * cs - ii * sn);
+  const float o1 = f32(-rr * sn + ii * cs);
+  constexpr int n2 = 2 * NFFT;
+  if (REV) { dst[n2 - 1 - 2 * i] = o0; dst[2 * i] = o1; }
+  else { dst[2 * i] = o0; dst[n2 - 1 - 2 * i] = o1; }
+}
+
+__global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) {
+  __shared__ LongLds S;
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x % L.channels;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
+  const float *__restrict__ pcm = L.pcm[ch];
+
+  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
+  for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
+  for (int i = lane; i < 256; i += 64) { S.in0[i] = 0.0f; S.in1[i] = 0.0f; }
+  for (int i = lane; i < 512; i += 64) S.in2[i] = 0.0f;
+  __syncthreads();
+
+  const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
+  for (int64_t f = f0 - 1; f < f_end; ++f) {
+    if (f < -(int64_t)L.halo_frames) continue;   // before the stream start: the zero state stays
+    const bool emit = (f >= f0);
+    TablesPtr T = tables_for_this_frame(L.tables);
+
+    // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
+    {
+      const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f * 512);
+      const float4 a = p4[lane], b = p4[64 + lane];
+      double *w1 = S.u.q.w1;
+      if (lane < 46) w1[pidx(lane)] = S.d1[lane];
+      const int e0 = 46 + 4 * lane;
+      *reinterpret_cast<double2 *>(&w1[pidx(e0)]) = make_double2((double)a.x, (double)a.y);
+      *reinterpret_cast<double2 *>(&w1[pidx(e0 + 2)]) = make_double2((double)a.z, (double)a.w);
+      *reinterpret_cast<double2 *>(&w1[pidx(e0 + 256)]) = make_double2((double)b.x, (double)b.y);
+      *reinterpret_cast<double2 *>(&w1[pidx(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
+    }
+    __syncthreads();
+    {
+      double ev[4], od[4];
+      qmf_analysis_core<4>(S.u.q.w1, lane, T, ev, od);
+      double *w2 = S.u.q.w2;
+      if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q.w1[pidx(512 + lane)]; }
+      float lo[4];
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        lo[d] = f32(ev[d] + od[d]);                       // qmf.js:44-45
+        S.hbuf[39 + 4 * lane + d] = f32(ev[d] - od[d]);   // high band enters behind its 39-sample delay
+      }
+      *reinterpret_cast<double2 *>(&w2[pidx(46 + 4 * lane)]) = make_double2((double)lo[0], (double)lo[1]);
+      *reinterpret_cast<double2 *>(&w2[pidx(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
+    }
+    __syncthreads();
+    {
+      double ev[2], od[2];
+      qmf_analysis_core<2>(S.u.q.w2, lane, T, ev, od);
+      *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
+      *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
+      *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
+      if (lane < 46) S.d2[lane] = S.u.q.w2[pidx(256 + lane)];
+    }
+    __syncthreads();
+    {
+      float keep = 0.0f;
+      if (lane < 39) keep = S.hbuf[256 + lane];
+      __syncthreads();
+      if (lane < 39) S.hbuf[lane] = keep;
+    }
+    if (emit && L.bands) {
+      float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
+      const float4 *src = reinterpret_cast<const float4 *>(S.band);
+      dst[lane] = src[lane];
+      dst[64 + lane] = src[64 + lane];
+    }
+
+    // ---------------- mdctStage, long blocks (encoder.js:228-258, 309-316) ----------------
+    // tail of every band: windowed copy into this frame's MDCT input, overlap for the next frame
+    float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;
+    if (lane < 32) {
+      const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
+      const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
+      ov0 = f32(w_lo * x0); ov1 = f32(w_lo * x1); ov2 = f32(w_lo * x2);
+      if (emit) {
+        S.in0[80 + 96 + lane] = f32(x0 * w_hi);
+        S.in1[80 + 96 + lane] = f32(x1 * w_hi);
+        S.in2[144 + 224 + lane] = f32(x2 * w_hi);
+      }
+    }
+    if (!emit) {
+      if (lane < 32) { S.in0[48 + lane] = ov0; S.in1[48 + lane] = ov1; S.in2[112 + lane] = ov2; }
+      __syncthreads();
+      continue;
+    }
+    // body of every band (everything before the tail) straight into the MDCT inputs
+    if (lane < 48) {
+      *reinterpret_cast<float2 *>(&S.in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
+      *reinterpret_cast<float2 *>(&S.in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+    }
+    if (lane < 56) *reinterpret_cast<float4 *>(&S.in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
+    __syncthreads();
+    float2 *z = S.u.m.z;
+    mdct_pre<64, 6>(S.in0, T->mdct_fwd256, lane, z);
+    mdct_pre<64, 6>(S.in1, T->mdct_fwd256, lane, z + 64);
+    mdct_pre<128, 7>(S.in2, T->mdct_fwd512, lane, z + 128);
+    mdct_pre<128, 7>(S.in2, T->mdct_fwd512, lane + 64, z + 128);
+    __syncthreads();
+    if (lane < 32) { S.in0[48 + lane] = ov0; S.in1[48 + lane] = ov1; S.in2[112 + lane] = ov2; }
+    // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
+    fft_butterfly<1>(z, lane, T); fft_butterfly<1>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<2>(z, lane, T); fft_butterfly<2>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<4>(z, lane, T); fft_butterfly<4>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<8>(z, lane, T); fft_butterfly<8>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<16>(z, lane, T); fft_butterfly<16>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<32>(z, lane, T); fft_butterfly<32>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<64>(z + 128, lane, T); __syncthreads();
+    float *coef = S.u.m.coef;
+    mdct_post<64, false>(z, T->mdct_fwd256, lane, coef);
+    mdct_post<64, true>(z + 64, T->mdct_fwd256, lane, coef + 128);
+    mdct_post<128, true>(z + 128, T->mdct_fwd512, lane, coef + 256);
+    mdct_post<128, true>(z + 128, T->mdct_fwd512, lane + 64, coef + 256);
+    __syncthreads();
+
+    // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+    const int64_t unit = f * L.channels + ch;
+    {
+      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+      const float4 *src = reinterpret_cast<const float4 *>(coef);
+      dst[lane] = src[lane];
+      dst[64 + lane] = src[64 + lane];
+    }
+    if (lane < 52) {
+      const int start = kStartLong[lane];
+      const int n = kSpecs[lane];
+      float mx = 0.0f;
+      for (int j = 0; j < n; j++) {
+        const float a = fabsf(coef[start + j]);
+        if (a > mx) mx = a;
+      }
+      S.sfi[lane] = (uint8_t)scale_factor_index(mx, T);
+    } else {
+      S.sfi[lane] = 0;
+    }
+    __syncthreads();
+    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================
 // bit allocation : allocateBits (bitallocation.js:74-142) as three small kernels
 // =====================================================================================================
 // The reference runs the greedy heap (distributeBitsRDO, :203-281) for all 8 candidate BFU counts and
@@ -1117,6 +1325,10 @@ void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t strea
   const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
   if (detect) hipLaunchKernelGGL(k_analysis<true>, grid, block, 0, stream, L);
   else hipLaunchKernelGGL(k_analysis<false>, grid, block, 0, stream, L);
+}
+void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream) {
+  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
+  hipLaunchKernelGGL(k_analysis_long, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
 }
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
