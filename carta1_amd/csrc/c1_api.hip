@@ -313,6 +313,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.cand = ctx->d_cand;
     L.work_count = ctx->d_work;
     L.work_list = ctx->d_work + 4;
+    { const char *dbg = getenv("C1_DEBUG"); L.debug = dbg ? atoi(dbg) : 0; }
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     const bool all_long = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&
@@ -434,7 +435,7 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   delete h;
   if (me != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "table upload: %s", hipGetErrorString(me)); }
   const char *env = getenv("C1_CHUNK_FRAMES");
-  ctx->chunk_frames = env ? atoll(env) : 32768;
+  ctx->chunk_frames = env ? atoll(env) : 131072;
   if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
   *out = ctx;
   return C1_OK;

@@ -973,72 +973,135 @@ __device__ __forceinline__ void put_bits_be(uint32_t *words, int pos, uint32_t v
   }
 }
 
-__global__ __launch_bounds__(C1_WAVE) void k_pack(C1EncodeLaunch L) {
-  __shared__ uint32_t words[56];
-  __shared__ int bit_off[53];
-  __shared__ uint8_t wl_s[52], sfi_s[64];
+// wave-level fence: LDS operations of one wave execute in issue order, so lanes of the same wave only
+// need the compiler not to reorder across this point (no s_barrier: waves of a block run independently)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kPackWaves = 4;            // independent waves per workgroup, one sound unit at a time each
+constexpr int kPackBlocks = 2048;        // persistent grid: waves stride over the units
+
+struct PackLds {
+  uint32_t words[56];         // the unit as big-endian 32-bit groups
+  uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
+  double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
+};
+
+// One wave per sound unit.  A lane owns 8 consecutive coefficient slots (BFU-major order == bitstream
+// order), quantizes them (quantization.js:34-56) and appends the mantissas MSB-first to a 64-bit
+// accumulator (serialization.js:79-91).  Completed 32-bit groups that lie wholly inside the lane's bit
+// range are plain LDS stores; only the first and last, which neighbours share, are atomic ORs.
+__global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L) {
+  __shared__ PackLds lds[kPackWaves];
   TablesPtr T = C1_TABLES(L.tables);
-  const int lane = threadIdx.x;
-  const int64_t unit = blockIdx.x;
-  const uint64_t *al = reinterpret_cast<const uint64_t *>(L.alloc + unit * kAllocBytes);
-  const uint64_t a3 = al[3];
-  const bool fallback = (a3 >> 59) & 1;
-  const int amount = (int)(a3 >> 60) & 7;
-  const int n = kAmounts[amount];
-  if (lane < 16) reinterpret_cast<uint32_t *>(sfi_s)[lane] = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes)[lane];
-  if (lane < 56) words[lane] = 0;
-  int wl = 0;
-  if (lane < 52) {
-    const uint64_t word = al[lane >> 4];
-    wl = lane < n ? (int)((word >> ((lane & 15) * 4)) & 15) : 0;
-    wl_s[lane] = (uint8_t)wl;
-  }
-  __syncthreads();
-  const int modes = sfi_s[52];
-  const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
-  // bit offset of every BFU's mantissas: exclusive prefix sum of bits*size over the wave
-  int mybits = (lane < n) ? wl_bits(wl) * (int)kSpecs[lane < 52 ? lane : 0] : 0;
-  int scan = mybits;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(scan, d);
-    if (lane >= d) scan += o;
-  }
-  if (lane < 52) bit_off[lane] = 16 + 10 * n + scan - mybits;
-  // header and per-BFU indices (serialization.js:46-77)
-  if (lane == 0) {
-    const uint32_t header = ((uint32_t)(2 - m0) << 14) | ((uint32_t)(2 - m1) << 12) | ((uint32_t)(3 - m2) << 10) | ((uint32_t)amount << 5);
-    atomicOr(&words[0], (header & 0xffffu) << 16);
-  }
-  if (lane < n) {
-    put_bits_be(words, 16 + 4 * lane, (uint32_t)wl, 4);
-    put_bits_be(words, 16 + 4 * n + 6 * lane, fallback ? 0u : (uint32_t)sfi_s[lane], 6);
-  }
-  __syncthreads();
-  // mantissas: coefficient slots in BFU-major order, 8 per lane
-  const float *coefs = L.coefs + (unit << 9);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PackLds &S = lds[wave];
+  // which BFU / which coefficient inside it each of this lane's 8 slots is: unit-invariant
+  int slot_b[8], slot_j[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) {
-    const int p = lane + 64 * m;
-    const int b = bfu_of_slot(p);
-    if (b >= n) continue;
-    const int w = wl_s[b];
-    if (w == 0) continue;
-    const int bits = w + 1;
-    const int j = p - kBfuFirst[b];
-    const int s = fallback ? 0 : sfi_s[b];
-    int32_t y = 0;
-    if (s != 0) {
-      const int mode = b >= 36 ? m2 : (b >= 20 ? m1 : m0);
-      const double x = (double)coefs[bfu_start(b, mode) + j] * T->norm[s * 16 + w];
-      const int32_t range = (1 << (bits - 1)) - 1;
-      y = to_int32(x + (x >= 0 ? 0.5 : -0.5));                // round half away from zero, then `| 0`
-      y = y > range ? range : (y < -range ? -range : y);
-    }
-    put_bits_be(words, bit_off[b] + j * bits, (uint32_t)y & ((1u << bits) - 1u), bits);
+    const int p = 8 * lane + m;
+    slot_b[m] = bfu_of_slot(p);
+    slot_j[m] = p - kBfuFirst[slot_b[m]];
   }
-  __syncthreads();
-  if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(words[lane]);
+  const int my_size = lane < 52 ? kSpecs[lane] : 0;
+  const int64_t units_total = L.frames * L.channels;
+  for (int64_t unit_v = (int64_t)blockIdx.x * kPackWaves + wave; unit_v < units_total; unit_v += (int64_t)gridDim.x * kPackWaves) {
+    const int64_t unit = ((int64_t)__builtin_amdgcn_readfirstlane((int)(unit_v >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_v);     // wave-uniform: scalar loads below
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes);
+    const uint32_t *side = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes);
+    const uint32_t a7 = al[7];
+    const bool fallback = (a7 >> 27) & 1;
+    const int amount = (int)(a7 >> 28) & 7;
+    const int n = kAmounts[amount];
+    const int modes = (int)(side[13] & 0xff);
+    const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
+    if (lane < 56) S.words[lane] = 0;
+    int wl = 0, s = 0;
+    if (lane < 52) {
+      wl = lane < n ? (int)((al[lane >> 3] >> ((lane & 7) * 4)) & 15) : 0;
+      s = fallback ? 0 : (int)((side[lane >> 2] >> ((lane & 3) * 8)) & 63);
+    }
+    // bit offset of every BFU's mantissas: exclusive prefix sum of bits*size over the wave
+    const int bits_b = wl_bits(wl);
+    const int mybits = bits_b * my_size;
+    int scan = mybits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(scan, d);
+      if (lane >= d) scan += o;
+    }
+    if (lane < 52) {
+      const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
+      S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)bfu_start(lane, mode) << 16);
+      S.normd[lane] = (s != 0 && bits_b != 0) ? T->norm[s * 16 + wl] : 0.0;
+    }
+    wave_sync();
+    // header (serialization.js:46-53) and word-length indices (:55-64): the 4-bit indices are already
+    // packed two per byte in the allocation record, low nibble first; the unit wants the high nibble first
+    if (lane < 8) {
+      auto wl_be = [&](int q) -> uint32_t {           // word-length bytes 4q..4q+3 as a big-endian word
+        if (q < 0 || q > 6) return 0u;
+        const uint32_t x = al[q];
+        return __builtin_bswap32(((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu));
+      };
+      const uint32_t header = ((uint32_t)(2 - m0) << 14) | ((uint32_t)(2 - m1) << 12) | ((uint32_t)(3 - m2) << 10) | ((uint32_t)amount << 5);
+      const uint32_t prev = lane == 0 ? (header & 0xffffu) : wl_be(lane - 1);
+      atomicOr(&S.words[lane], (prev << 16) | (wl_be(lane) >> 16));
+    }
+    // scale-factor indices (:66-77): four 6-bit fields = 24 bits per lane
+    if (lane < (n >> 2)) {
+      const uint32_t q = fallback ? 0u : side[lane];
+      const uint32_t t = ((q & 63u) << 18) | (((q >> 8) & 63u) << 12) | (((q >> 16) & 63u) << 6) | ((q >> 24) & 63u);
+      put_bits_be(S.words, 16 + 4 * n + 24 * lane, t, 24);
+    }
+    // mantissas
+    const float *coefs = L.coefs + (unit << 9);
+    float x[8];
+    if (modes == 0) {   // all long: coefficient order == slot order
+      const float4 a = reinterpret_cast<const float4 *>(coefs)[2 * lane], c = reinterpret_cast<const float4 *>(coefs)[2 * lane + 1];
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) x[m] = coefs[(S.desc[slot_b[m]] >> 16) + slot_j[m]];
+    }
+    uint64_t acc = 0;
+    int cnt = -1, wi = 0;
+    bool first = true;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const uint32_t dsc = S.desc[slot_b[m]];
+      const int bits = dsc & 31;
+      if (cnt < 0 && bits != 0) {                               // the lane's first coded slot fixes its bit cursor
+        const int pos = (int)((dsc >> 5) & 0x7ff) + slot_j[m] * bits;
+        cnt = pos & 31;                                         // phantom zero bits in front: a neighbour's bits
+        wi = pos >> 5;
+      }
+      const double xs = (double)x[m] * S.normd[slot_b[m]];
+      const double v = xs + (xs >= 0 ? 0.5 : -0.5);            // round half away from zero ...
+      int32_t y = (int32_t)v;                                  // ... then `| 0`: truncation; exact wrap below
+      if (__builtin_expect(!(fabs(v) < 2147483648.0), 0)) y = to_int32(v);
+      const int32_t range = (1 << (bits > 0 ? bits - 1 : 0)) - 1;
+      y = y > range ? range : (y < -range ? -range : y);
+      acc = (acc << bits) | ((uint32_t)y & ((1u << bits) - 1u));
+      cnt += bits != 0 ? bits : 0;
+      if (cnt >= 32) {                                          // a 32-bit group is complete
+        cnt -= 32;
+        const uint32_t w = (uint32_t)(acc >> cnt);
+        acc &= (1ull << cnt) - 1ull;
+        if (first) atomicOr(&S.words[wi], w); else S.words[wi] = w;
+        first = false;
+        wi++;
+      }
+    }
+    if (cnt > 0) atomicOr(&S.words[wi], (uint32_t)(acc << (32 - cnt)));
+    wave_sync();
+    if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
+    wave_sync();
+  }
 }
 
 // =====================================================================================================
@@ -1339,7 +1402,7 @@ void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, L);
 }
 void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream) {
-  hipLaunchKernelGGL(k_pack, dim3((unsigned)(L.frames * L.channels)), dim3(C1_WAVE), 0, stream, L);
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), dim3(C1_WAVE * kPackWaves), 0, stream, L);
 }
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFrames - 1) / kRunFrames;
