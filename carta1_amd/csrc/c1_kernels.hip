@@ -496,13 +496,18 @@ struct alignas(16) LongLds {
   double d2[46];                 // stage-2 QMF delay line
   alignas(16) float band[512];   // low128 | mid128 | high256, raw
   alignas(16) float hbuf[296];   // delayed high band: [0,39) tail of the previous frame, [39,295) this frame
-  alignas(16) float in0[256];    // MDCT-256 input, low band:  0 x48 | overlap32 | samples128 | 0 x48
-  alignas(16) float in1[256];    // MDCT-256 input, mid band
-  alignas(16) float in2[512];    // MDCT-512 input, high band: 0 x112 | overlap32 | samples256 | 0 x112
   alignas(4) uint8_t sfi[64];
+  // scratch with disjoint lifetimes inside one frame (10 KiB per wave in total: 16 waves per CU)
   union alignas(16) {
-    struct { alignas(16) double w1[592]; alignas(16) double w2[320]; } q;
-    struct { alignas(16) float2 z[256]; alignas(16) float coef[512]; } m;
+    struct { alignas(16) double w1[592]; } q1;     // stage-1 QMF work buffer
+    struct { alignas(16) double w2[320]; } q2;     // stage-2 QMF work buffer (after stage 1 has read w1)
+    struct {
+      union alignas(16) {
+        struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // MDCT inputs
+        struct { alignas(16) float coef[512]; } c;                                                           // coefficients (after the pre-twiddle)
+      } a;
+      alignas(16) float2 z[256];                                                                             // FFT points
+    } m;
   } u;
 };
 
@@ -550,17 +555,17 @@ __device__ __forceinline__ void mdct_post(const float2 *z, const __attribute__((
   else { dst[2 * i] = o0; dst[n2 - 1 - 2 * i] = o1; }
 }
 
-__global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) {
   __shared__ LongLds S;
-  const int lane = threadIdx.x;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
   const int ch = blockIdx.x % L.channels;
   const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
   const float *__restrict__ pcm = L.pcm[ch];
 
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
-  for (int i = lane; i < 256; i += 64) { S.in0[i] = 0.0f; S.in1[i] = 0.0f; }
-  for (int i = lane; i < 512; i += 64) S.in2[i] = 0.0f;
+  float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
@@ -568,12 +573,13 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) 
     if (f < -(int64_t)L.halo_frames) continue;   // before the stream start: the zero state stays
     const bool emit = (f >= f0);
     TablesPtr T = tables_for_this_frame(L.tables);
+    lane = lane_for_this_frame(lane0);
 
     // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
     {
       const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f * 512);
       const float4 a = p4[lane], b = p4[64 + lane];
-      double *w1 = S.u.q.w1;
+      double *w1 = S.u.q1.w1;
       if (lane < 46) w1[pidx(lane)] = S.d1[lane];
       const int e0 = 46 + 4 * lane;
       *reinterpret_cast<double2 *>(&w1[pidx(e0)]) = make_double2((double)a.x, (double)a.y);
@@ -584,9 +590,9 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) 
     __syncthreads();
     {
       double ev[4], od[4];
-      qmf_analysis_core<4>(S.u.q.w1, lane, T, ev, od);
-      double *w2 = S.u.q.w2;
-      if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q.w1[pidx(512 + lane)]; }
+      qmf_analysis_core<4>(S.u.q1.w1, lane, T, ev, od);
+      double *w2 = S.u.q2.w2;
+      if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx(512 + lane)]; }
       float lo[4];
 #pragma unroll
       for (int d = 0; d < 4; d++) {
@@ -599,11 +605,11 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) 
     __syncthreads();
     {
       double ev[2], od[2];
-      qmf_analysis_core<2>(S.u.q.w2, lane, T, ev, od);
+      qmf_analysis_core<2>(S.u.q2.w2, lane, T, ev, od);
       *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
       *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
       *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
-      if (lane < 46) S.d2[lane] = S.u.q.w2[pidx(256 + lane)];
+      if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx(256 + lane)];
     }
     __syncthreads();
     {
@@ -621,36 +627,43 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) 
 
     // ---------------- mdctStage, long blocks (encoder.js:228-258, 309-316) ----------------
     // tail of every band: windowed copy into this frame's MDCT input, overlap for the next frame
-    float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;
+    float *in0 = S.u.m.a.i.in0, *in1 = S.u.m.a.i.in1, *in2 = S.u.m.a.i.in2;
+    float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
     if (lane < 32) {
       const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
       const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
-      ov0 = f32(w_lo * x0); ov1 = f32(w_lo * x1); ov2 = f32(w_lo * x2);
+      nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
       if (emit) {
-        S.in0[80 + 96 + lane] = f32(x0 * w_hi);
-        S.in1[80 + 96 + lane] = f32(x1 * w_hi);
-        S.in2[144 + 224 + lane] = f32(x2 * w_hi);
+        in0[48 + lane] = ov0; in1[48 + lane] = ov1; in2[112 + lane] = ov2;     // overlap saved by the previous frame
+        in0[80 + 96 + lane] = f32(x0 * w_hi);
+        in1[80 + 96 + lane] = f32(x1 * w_hi);
+        in2[144 + 224 + lane] = f32(x2 * w_hi);
       }
     }
-    if (!emit) {
-      if (lane < 32) { S.in0[48 + lane] = ov0; S.in1[48 + lane] = ov1; S.in2[112 + lane] = ov2; }
-      __syncthreads();
-      continue;
+    ov0 = nov0; ov1 = nov1; ov2 = nov2;
+    if (!emit) { __syncthreads(); continue; }
+    // zero regions and the body of every band (everything before the tail) straight into the MDCT inputs
+    {
+      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (lane < 48) {
+        float *inb = lane < 24 ? in0 : in1;
+        const int q = lane < 24 ? lane : lane - 24;                 // 24 float4 per band: [0,48) and [208,256)
+        *reinterpret_cast<float4 *>(&inb[q < 12 ? 4 * q : 208 + 4 * (q - 12)]) = zero4;
+      }
+      if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
+      if (lane < 48) {
+        *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
+        *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+      }
+      if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
     }
-    // body of every band (everything before the tail) straight into the MDCT inputs
-    if (lane < 48) {
-      *reinterpret_cast<float2 *>(&S.in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
-      *reinterpret_cast<float2 *>(&S.in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
-    }
-    if (lane < 56) *reinterpret_cast<float4 *>(&S.in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
     __syncthreads();
     float2 *z = S.u.m.z;
-    mdct_pre<64, 6>(S.in0, T->mdct_fwd256, lane, z);
-    mdct_pre<64, 6>(S.in1, T->mdct_fwd256, lane, z + 64);
-    mdct_pre<128, 7>(S.in2, T->mdct_fwd512, lane, z + 128);
-    mdct_pre<128, 7>(S.in2, T->mdct_fwd512, lane + 64, z + 128);
+    mdct_pre<64, 6>(in0, T->mdct_fwd256, lane, z);
+    mdct_pre<64, 6>(in1, T->mdct_fwd256, lane, z + 64);
+    mdct_pre<128, 7>(in2, T->mdct_fwd512, lane, z + 128);
+    mdct_pre<128, 7>(in2, T->mdct_fwd512, lane + 64, z + 128);
     __syncthreads();
-    if (lane < 32) { S.in0[48 + lane] = ov0; S.in1[48 + lane] = ov1; S.in2[112 + lane] = ov2; }
     // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
     fft_butterfly<1>(z, lane, T); fft_butterfly<1>(z + 128, lane, T); __syncthreads();
     fft_butterfly<2>(z, lane, T); fft_butterfly<2>(z + 128, lane, T); __syncthreads();
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_analysis_long(C1EncodeLaunch L) 
     fft_butterfly<16>(z, lane, T); fft_butterfly<16>(z + 128, lane, T); __syncthreads();
     fft_butterfly<32>(z, lane, T); fft_butterfly<32>(z + 128, lane, T); __syncthreads();
     fft_butterfly<64>(z + 128, lane, T); __syncthreads();
-    float *coef = S.u.m.coef;
+    float *coef = S.u.m.a.c.coef;
     mdct_post<64, false>(z, T->mdct_fwd256, lane, coef);
     mdct_post<64, true>(z + 64, T->mdct_fwd256, lane, coef + 128);
     mdct_post<128, true>(z + 128, T->mdct_fwd512, lane, coef + 256);
