@@ -161,14 +161,17 @@ struct c1_ctx {
   C1DevEncOpts *d_opts = nullptr;
   c1_encode_options last_opts;
   bool have_opts = false;
-  // workspace for one chunk
+  // workspace: two chunk-sized sets, so chunk i+1's analysis overlaps chunk i's allocation and packing
   int64_t ws_units = 0;
-  float *d_coefs = nullptr;
-  uint8_t *d_side = nullptr;
-  uint8_t *d_alloc = nullptr;
-  uint8_t *d_cand = nullptr;
-  uint32_t *d_work = nullptr;      // [0] = count, list from [4]
+  float *d_coefs[2] = {nullptr, nullptr};
+  uint8_t *d_side[2] = {nullptr, nullptr};
+  uint8_t *d_alloc[2] = {nullptr, nullptr};
+  uint8_t *d_cand[2] = {nullptr, nullptr};
+  uint32_t *d_work[2] = {nullptr, nullptr};      // [0] = count, list from [4]
   int64_t chunk_frames = 0;
+  bool pipeline = true;
+  hipStream_t s_ana = nullptr, s_rest = nullptr;  // internal streams of the two pipeline halves
+  hipEvent_t ev_in = nullptr, ev_ana[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
   // profiling
   bool profiling = false;
   std::vector<Timing> timings;
@@ -188,15 +191,29 @@ int ctx_bind(c1_ctx *ctx) {
   return C1_OK;
 }
 
+void free_workspace(c1_ctx *ctx) {
+  for (int p = 0; p < 2; p++) {
+    if (ctx->d_coefs[p]) (void)hipFree(ctx->d_coefs[p]);
+    if (ctx->d_side[p]) (void)hipFree(ctx->d_side[p]);
+    if (ctx->d_alloc[p]) (void)hipFree(ctx->d_alloc[p]);
+    if (ctx->d_cand[p]) (void)hipFree(ctx->d_cand[p]);
+    if (ctx->d_work[p]) (void)hipFree(ctx->d_work[p]);
+    ctx->d_coefs[p] = nullptr; ctx->d_side[p] = nullptr; ctx->d_alloc[p] = nullptr; ctx->d_cand[p] = nullptr; ctx->d_work[p] = nullptr;
+  }
+  ctx->ws_units = 0;
+}
+
 int ensure_workspace(c1_ctx *ctx, int64_t units) {
   if (units <= ctx->ws_units) return C1_OK;
-  if (ctx->d_coefs) { hipFree(ctx->d_coefs); hipFree(ctx->d_side); hipFree(ctx->d_alloc); hipFree(ctx->d_cand); hipFree(ctx->d_work); }
-  ctx->d_coefs = nullptr; ctx->d_side = nullptr; ctx->d_alloc = nullptr; ctx->d_cand = nullptr; ctx->d_work = nullptr; ctx->ws_units = 0;
-  HIP_TRY(hipMalloc(&ctx->d_coefs, (size_t)units * 512 * sizeof(float)));
-  HIP_TRY(hipMalloc(&ctx->d_side, (size_t)units * kSideBytes));
-  HIP_TRY(hipMalloc(&ctx->d_alloc, (size_t)units * kAllocBytes));
-  HIP_TRY(hipMalloc(&ctx->d_cand, (size_t)units * kCandidateBytes));
-  HIP_TRY(hipMalloc(&ctx->d_work, ((size_t)units * 7 + 4) * sizeof(uint32_t)));
+  HIP_TRY(hipDeviceSynchronize());
+  free_workspace(ctx);
+  for (int p = 0; p < 2; p++) {
+    HIP_TRY(hipMalloc(&ctx->d_coefs[p], (size_t)units * 512 * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_side[p], (size_t)units * kSideBytes));
+    HIP_TRY(hipMalloc(&ctx->d_alloc[p], (size_t)units * kAllocBytes));
+    HIP_TRY(hipMalloc(&ctx->d_cand[p], (size_t)units * kCandidateBytes));
+    HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 7 + 4) * sizeof(uint32_t)));
+  }
   ctx->ws_units = units;
   return C1_OK;
 }
@@ -238,16 +255,17 @@ struct ScopedTiming {
   c1_ctx *ctx;
   Timing t;
   bool on;
-  ScopedTiming(c1_ctx *c, int kind) : ctx(c), on(c->profiling) {
+  hipStream_t stream;
+  ScopedTiming(c1_ctx *c, int kind, hipStream_t s = nullptr) : ctx(c), on(c->profiling), stream(s ? s : c->stream) {
     if (!on) return;
     t.kind = kind;
     t.start = take_event(ctx);
     t.stop = take_event(ctx);
-    hipEventRecord(t.start, ctx->stream);
+    (void)hipEventRecord(t.start, stream);
   }
   ~ScopedTiming() {
     if (!on) return;
-    hipEventRecord(t.stop, ctx->stream);
+    (void)hipEventRecord(t.stop, stream);
     ctx->timings.push_back(t);
   }
 };
@@ -297,8 +315,20 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   const bool taps = coefs_tap || side_tap || alloc_tap;
   if ((rc = ensure_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (taps && (!coefs_tap || !side_tap || !alloc_tap)) return fail(C1_ERR_ARG, "coefs, side and alloc taps must be given together");
-  for (int64_t f0 = 0; f0 < frames; f0 += taps ? frames : chunk) {
+  // Two-stage software pipeline over chunks: the analysis of chunk i+1 (fp64-VALU bound) runs on one
+  // stream while allocation + packing of chunk i (latency bound) run on another, each chunk on its own
+  // half of the workspace.  Everything is ordered after the caller's stream and joined back into it.
+  const bool piped = ctx->pipeline && !taps && frames > chunk;
+  hipStream_t sA = piped ? ctx->s_ana : ctx->stream, sB = piped ? ctx->s_rest : ctx->stream;
+  if (piped) {
+    HIP_TRY(hipEventRecord(ctx->ev_in, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_in, 0));
+    HIP_TRY(hipStreamWaitEvent(sB, ctx->ev_in, 0));
+  }
+  int64_t index = 0;
+  for (int64_t f0 = 0; f0 < frames; f0 += taps ? frames : chunk, ++index) {
     const int64_t n = taps ? frames : std::min(chunk, frames - f0);
+    const int p = piped ? (int)(index & 1) : 0;
     C1EncodeLaunch L;
     memset(&L, 0, sizeof L);
     for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c] + f0 * 512;
@@ -307,24 +337,36 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.halo_frames = (int)std::min<int64_t>(2, f0 + halo_frames);
     L.tables = ctx->d_tables;
     L.opts = ctx->d_opts;
-    L.coefs = taps ? coefs_tap : ctx->d_coefs;
-    L.side = taps ? side_tap : ctx->d_side;
-    L.alloc = taps ? alloc_tap : ctx->d_alloc;
-    L.cand = ctx->d_cand;
-    L.work_count = ctx->d_work;
-    L.work_list = ctx->d_work + 4;
+    L.coefs = taps ? coefs_tap : ctx->d_coefs[p];
+    L.side = taps ? side_tap : ctx->d_side[p];
+    L.alloc = taps ? alloc_tap : ctx->d_alloc[p];
+    L.cand = ctx->d_cand[p];
+    L.work_count = ctx->d_work[p];
+    L.work_list = ctx->d_work[p] + 4;
     { const char *dbg = getenv("C1_DEBUG"); L.debug = dbg ? atoi(dbg) : 0; }
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     const bool all_long = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&
                           opts->fixed_block_modes[2] == 0 && !getenv("C1_NO_FAST_LONG");
+    if (piped && index >= 2) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_free[p], 0));   // workspace half p is free again
     {
-      ScopedTiming t(ctx, K_ANALYSIS);
-      if (all_long) c1k_launch_analysis_long(L, ctx->stream);
-      else c1k_launch_analysis(L, detect, ctx->stream);
+      ScopedTiming t(ctx, K_ANALYSIS, sA);
+      if (all_long) c1k_launch_analysis_long(L, sA);
+      else c1k_launch_analysis(L, detect, sA);
     }
-    { ScopedTiming t(ctx, K_ALLOCATE); c1k_launch_allocate(L, ctx->stream); }
-    if (L.units) { ScopedTiming t(ctx, K_PACK); c1k_launch_pack(L, ctx->stream); }
+    if (piped) {
+      HIP_TRY(hipEventRecord(ctx->ev_ana[p], sA));
+      HIP_TRY(hipStreamWaitEvent(sB, ctx->ev_ana[p], 0));
+    }
+    { ScopedTiming t(ctx, K_ALLOCATE, sB); c1k_launch_allocate(L, sB); }
+    if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, sB); }
+    if (piped) HIP_TRY(hipEventRecord(ctx->ev_free[p], sB));
+  }
+  if (piped) {
+    HIP_TRY(hipEventRecord(ctx->ev_end[0], sA));
+    HIP_TRY(hipEventRecord(ctx->ev_end[1], sB));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_end[0], 0));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_end[1], 0));
   }
   HIP_TRY(hipGetLastError());
   return C1_OK;
@@ -434,6 +476,19 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
   delete h;
   if (me != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "table upload: %s", hipGetErrorString(me)); }
+  {
+    hipError_t pe = hipStreamCreateWithFlags(&ctx->s_ana, hipStreamNonBlocking);
+    if (pe == hipSuccess) pe = hipStreamCreateWithFlags(&ctx->s_rest, hipStreamNonBlocking);
+    if (pe == hipSuccess) pe = hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming);
+    for (int p = 0; p < 2 && pe == hipSuccess; p++) {
+      pe = hipEventCreateWithFlags(&ctx->ev_ana[p], hipEventDisableTiming);
+      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&ctx->ev_free[p], hipEventDisableTiming);
+      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&ctx->ev_end[p], hipEventDisableTiming);
+    }
+    if (pe != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "pipeline streams: %s", hipGetErrorString(pe)); }
+    const char *pl = getenv("C1_PIPELINE");
+    ctx->pipeline = pl ? atoi(pl) != 0 : false;   // measured: no gain while one kernel's grid already owns every CU's LDS
+  }
   const char *env = getenv("C1_CHUNK_FRAMES");
   ctx->chunk_frames = env ? atoll(env) : 131072;
   if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
@@ -449,11 +504,16 @@ int c1_ctx_destroy(c1_ctx *ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->d_tables) hipFree(ctx->d_tables);
   if (ctx->d_opts) hipFree(ctx->d_opts);
-  if (ctx->d_coefs) hipFree(ctx->d_coefs);
-  if (ctx->d_side) hipFree(ctx->d_side);
-  if (ctx->d_alloc) hipFree(ctx->d_alloc);
-  if (ctx->d_cand) hipFree(ctx->d_cand);
-  if (ctx->d_work) hipFree(ctx->d_work);
+  (void)hipDeviceSynchronize();
+  free_workspace(ctx);
+  if (ctx->s_ana) (void)hipStreamDestroy(ctx->s_ana);
+  if (ctx->s_rest) (void)hipStreamDestroy(ctx->s_rest);
+  if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+  for (int p = 0; p < 2; p++) {
+    if (ctx->ev_ana[p]) (void)hipEventDestroy(ctx->ev_ana[p]);
+    if (ctx->ev_free[p]) (void)hipEventDestroy(ctx->ev_free[p]);
+    if (ctx->ev_end[p]) (void)hipEventDestroy(ctx->ev_end[p]);
+  }
   if (ctx->d_io) hipFree(ctx->d_io);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -569,16 +569,25 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
-  for (int64_t f = f0 - 1; f < f_end; ++f) {
-    if (f < -(int64_t)L.halo_frames) continue;   // before the stream start: the zero state stays
+  const int64_t f_first = (f0 - 1 < -(int64_t)L.halo_frames) ? f0 : f0 - 1;   // before the stream start the zero state stays
+  // the PCM of the next frame is fetched while the current one is processed (two 16-byte loads per lane)
+  float4 pre_a, pre_b;
+  {
+    const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
+    pre_a = p4[lane0]; pre_b = p4[64 + lane0];
+  }
+  for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = (f >= f0);
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
 
     // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
     {
-      const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f * 512);
-      const float4 a = p4[lane], b = p4[64 + lane];
+      const float4 a = pre_a, b = pre_b;
+      if (f + 1 < f_end) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
+        pre_a = p4[lane]; pre_b = p4[64 + lane];
+      }
       double *w1 = S.u.q1.w1;
       if (lane < 46) w1[pidx(lane)] = S.d1[lane];
       const int e0 = 46 + 4 * lane;
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
     __syncthreads();
     {
       double ev[4], od[4];
-      qmf_analysis_core<4>(S.u.q1.w1, lane, T, ev, od);
+      if (!(L.debug & 16)) qmf_analysis_core<4>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
       double *w2 = S.u.q2.w2;
       if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx(512 + lane)]; }
       float lo[4];
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
     __syncthreads();
     {
       double ev[2], od[2];
-      qmf_analysis_core<2>(S.u.q2.w2, lane, T, ev, od);
+      if (!(L.debug & 16)) qmf_analysis_core<2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
       *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
       *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
       *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
@@ -659,12 +668,15 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
     }
     __syncthreads();
     float2 *z = S.u.m.z;
+    if (!(L.debug & 32)) {
     mdct_pre<64, 6>(in0, T->mdct_fwd256, lane, z);
     mdct_pre<64, 6>(in1, T->mdct_fwd256, lane, z + 64);
     mdct_pre<128, 7>(in2, T->mdct_fwd512, lane, z + 128);
     mdct_pre<128, 7>(in2, T->mdct_fwd512, lane + 64, z + 128);
+    }
     __syncthreads();
     // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
+    if (!(L.debug & 8)) {
     fft_butterfly<1>(z, lane, T); fft_butterfly<1>(z + 128, lane, T); __syncthreads();
     fft_butterfly<2>(z, lane, T); fft_butterfly<2>(z + 128, lane, T); __syncthreads();
     fft_butterfly<4>(z, lane, T); fft_butterfly<4>(z + 128, lane, T); __syncthreads();
@@ -672,11 +684,14 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
     fft_butterfly<16>(z, lane, T); fft_butterfly<16>(z + 128, lane, T); __syncthreads();
     fft_butterfly<32>(z, lane, T); fft_butterfly<32>(z + 128, lane, T); __syncthreads();
     fft_butterfly<64>(z + 128, lane, T); __syncthreads();
+    }
     float *coef = S.u.m.a.c.coef;
+    if (!(L.debug & 32)) {
     mdct_post<64, false>(z, T->mdct_fwd256, lane, coef);
     mdct_post<64, true>(z + 64, T->mdct_fwd256, lane, coef + 128);
     mdct_post<128, true>(z + 128, T->mdct_fwd512, lane, coef + 256);
     mdct_post<128, true>(z + 128, T->mdct_fwd512, lane + 64, coef + 256);
+    }
     __syncthreads();
 
     // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
       dst[lane] = src[lane];
       dst[64 + lane] = src[64 + lane];
     }
-    if (lane < 52) {
+    if (lane < 52 && !(L.debug & 64)) {
       const int start = kStartLong[lane];
       const int n = kSpecs[lane];
       float mx = 0.0f;
