@@ -169,6 +169,8 @@ def main():
     if rank == 0:
         total_frames = frames * world * args.steps
         value = total_frames / elapsed
+        kernel_names = {'analysis': 'k_analysis_long' if modes == [0, 0, 0] else ('k_analysis<true>' if modes is None else 'k_analysis<false>'),
+                        'allocate': 'k_alloc_first+k_alloc_rest+k_alloc_select', 'pack': 'k_pack', 'decode': 'k_decode'}
         dom = max(kernel_ms, key=lambda k: kernel_ms[k]['ms_per_step'])
         dom_ms, dom_n = kernel_ms[dom]['ms_per_step'], max(1, kernel_ms[dom]['launches_per_step'])
         frames_per_launch = frames / dom_n
@@ -191,7 +193,7 @@ def main():
                                    % (args.signal, frames, args.modes, args.bias,
                                       'decode' if args.decode else 'encode to 212-byte units'),
                        'frames_per_gpu': frames, 'channels': 2, 'sharding': 'frame batch per GPU, no collectives'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': kernel_names.get(dom, 'k_' + dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_stereo_frame': BYTES_PER_STEREO_FRAME,
                          'stereo_frames_per_launch': frames_per_launch, 'avg_launch_ms': dom_ms / dom_n,
