@@ -82,9 +82,11 @@ __device__ __forceinline__ int bfu_of_slot(int p) {
 
 __device__ __forceinline__ float f32(double x) { return (float)x; }  // Float32Array store
 
-// index of double element e in a QMF work buffer: 2 pad doubles after every 32, so that the
-// 16-byte reads of a wave whose lanes are 32 or 64 bytes apart spread over all LDS banks
-__device__ __forceinline__ int pidx(int e) { return e + ((e >> 5) << 1); }
+// index of double element e in a QMF work buffer: 2 pad doubles after every 2^S, so that the 16-byte
+// window reads of a wave whose lanes are 64 bytes (4 outputs per lane, S = 3) or 32 bytes (2 outputs
+// per lane, S = 2) apart are bank-conflict free (tools/lds_model.py); the generic kernels use S = 5
+template <int S = 5>
+__device__ __forceinline__ int pidx(int e) { return e + ((e >> S) << 1); }
 
 // ---- QMF convolution core ------------------------------------------------------------------------
 // Analysis (qmf.js:33-47): output i needs work[2i .. 2i+47]:
@@ -92,7 +94,7 @@ __device__ __forceinline__ int pidx(int e) { return e + ((e >> 5) << 1); }
 // A lane owns D consecutive outputs i = D*lane+d, i.e. the 46+2D doubles from 2*D*lane, read
 // as 16-byte (even,odd) pairs u = 22+D .. 0; pair u feeds tap j = d+23-u of output d, so walking
 // u downwards adds the terms of every sum in the reference's order.
-template <int D>
+template <int D, int S = 5>
 __device__ __forceinline__ void qmf_analysis_core(const double *w, int lane, TablesPtr T,
                                                   double (&even)[D], double (&odd)[D]) {
   const int base = 2 * D * lane;
@@ -100,7 +102,7 @@ __device__ __forceinline__ void qmf_analysis_core(const double *w, int lane, Tab
   for (int d = 0; d < D; d++) even[d] = odd[d] = 0.0;
 #pragma unroll
   for (int u = 22 + D; u >= 0; --u) {
-    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx(base + 2 * u)]);
+    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx<S>(base + 2 * u)]);
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int j = d + 23 - u;
@@ -499,8 +501,8 @@ struct alignas(16) LongLds {
   alignas(4) uint8_t sfi[64];
   // scratch with disjoint lifetimes inside one frame (10 KiB per wave in total: 16 waves per CU)
   union alignas(16) {
-    struct { alignas(16) double w1[592]; } q1;     // stage-1 QMF work buffer
-    struct { alignas(16) double w2[320]; } q2;     // stage-2 QMF work buffer (after stage 1 has read w1)
+    struct { alignas(16) double w1[698]; } q1;     // stage-1 QMF work buffer, padded 2 per 8
+    struct { alignas(16) double w2[454]; } q2;     // stage-2 QMF work buffer (after stage 1 has read w1), padded 2 per 4
     struct {
       union alignas(16) {
         struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // MDCT inputs
@@ -589,36 +591,36 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
         pre_a = p4[lane]; pre_b = p4[64 + lane];
       }
       double *w1 = S.u.q1.w1;
-      if (lane < 46) w1[pidx(lane)] = S.d1[lane];
+      if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
       const int e0 = 46 + 4 * lane;
-      *reinterpret_cast<double2 *>(&w1[pidx(e0)]) = make_double2((double)a.x, (double)a.y);
-      *reinterpret_cast<double2 *>(&w1[pidx(e0 + 2)]) = make_double2((double)a.z, (double)a.w);
-      *reinterpret_cast<double2 *>(&w1[pidx(e0 + 256)]) = make_double2((double)b.x, (double)b.y);
-      *reinterpret_cast<double2 *>(&w1[pidx(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0)]) = make_double2((double)a.x, (double)a.y);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 2)]) = make_double2((double)a.z, (double)a.w);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 256)]) = make_double2((double)b.x, (double)b.y);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
     }
     __syncthreads();
     {
       double ev[4], od[4];
-      if (!(L.debug & 16)) qmf_analysis_core<4>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
+      if (!(L.debug & 16)) qmf_analysis_core<4, 3>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
       double *w2 = S.u.q2.w2;
-      if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx(512 + lane)]; }
+      if (lane < 46) { w2[pidx<2>(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx<3>(512 + lane)]; }
       float lo[4];
 #pragma unroll
       for (int d = 0; d < 4; d++) {
         lo[d] = f32(ev[d] + od[d]);                       // qmf.js:44-45
         S.hbuf[39 + 4 * lane + d] = f32(ev[d] - od[d]);   // high band enters behind its 39-sample delay
       }
-      *reinterpret_cast<double2 *>(&w2[pidx(46 + 4 * lane)]) = make_double2((double)lo[0], (double)lo[1]);
-      *reinterpret_cast<double2 *>(&w2[pidx(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
+      *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 4 * lane)]) = make_double2((double)lo[0], (double)lo[1]);
+      *reinterpret_cast<double2 *>(&w2[pidx<2>(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
     }
     __syncthreads();
     {
       double ev[2], od[2];
-      if (!(L.debug & 16)) qmf_analysis_core<2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
+      if (!(L.debug & 16)) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
       *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
       *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
       *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
-      if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx(256 + lane)];
+      if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx<2>(256 + lane)];
     }
     __syncthreads();
     {
