@@ -104,6 +104,26 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
       d->norm[s * 16 + wl] = (double)range / t.scale_factors[s];  // quantization.js:42-44
     }
   d->log1p10 = t.log1p_10;
+  // Float32 thresholds of findScaleFactor: for a binary32 m, m > SCALE_FACTORS[i] <=> m > floor_f32(SF[i]).
+  // The reference's table is 2^(i/3-21): every octave has the same two fraction patterns; verify, else
+  // the kernels fall back to comparing against the double table.
+  auto floor_f32_bits = [](double x) -> uint32_t {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, 0.0f);
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+  };
+  d->sf_fast = 1;
+  d->sf_m1 = floor_f32_bits(t.scale_factors[1]) & 0x7fffffu;
+  d->sf_m2 = floor_f32_bits(t.scale_factors[2]) & 0x7fffffu;
+  for (int i = 0; i < 64; i++) {
+    const uint32_t u = floor_f32_bits(t.scale_factors[i]);
+    const int e = (int)(u >> 23) - 127, want_e = i / 3 - 21;
+    const uint32_t frac = u & 0x7fffffu, want = i % 3 == 0 ? 0u : (i % 3 == 1 ? d->sf_m1 : d->sf_m2);
+    const bool exact_pow2 = i % 3 != 0 || (double)std::ldexp(1.0f, want_e) == t.scale_factors[i];
+    if (e != want_e || frac != want || !exact_pow2) d->sf_fast = 0;
+  }
 }
 
 // rank table of the Float32 heap priorities (bitallocation.js:226-231, 267-269)

@@ -22,7 +22,11 @@ struct C1DevTables {
   double scale_factors[64];
   double norm[64 * 16];      // quantRange(wl)/SCALE_FACTORS[sfi]   quantization.js:42-44
   double log1p10;
-  double pad_;
+  // fraction bits (23) of floor_f32(2^(1/3)) and floor_f32(2^(2/3)) when every octave of scale_factors
+  // shares them (always true for the reference's table); sf_fast = 0 selects the table compare
+  uint32_t sf_m1, sf_m2;
+  int32_t sf_fast;
+  int32_t pad_;
 };
 
 // ---- per-call encoder options in device form ---------------------------------------------------

@@ -166,6 +166,17 @@ __device__ __forceinline__ void fft_stages(float *re, float *im, int lane, Table
 
 __device__ __forceinline__ int bitrev(int k, int log2n) { return (int)(__brev((unsigned)k) >> (32 - log2n)); }
 
+// findScaleFactor on binary32 bit patterns: with SF[3q] = 2^(q-21) and the two in-between fraction
+// patterns m1 < m2 shared by every octave, the index is 3(e+21) + [frac > 0] + [frac > m1] + [frac > m2]
+__device__ __forceinline__ int scale_factor_index_fast(float maxabs, uint32_t m1, uint32_t m2) {
+  const uint32_t u = __float_as_uint(maxabs);
+  const int e = (int)(u >> 23) - 127;
+  const uint32_t frac = u & 0x7fffffu;
+  int r = 3 * (e + 21) + (frac > 0u ? 1 : 0) + (frac > m1 ? 1 : 0) + (frac > m2 ? 1 : 0);
+  r = r > 63 ? 63 : r;
+  return (e < -21) ? 0 : r;     // also zero, denormals and anything below 2^-21
+}
+
 // smallest i with m <= SCALE_FACTORS[i], clamped to [0,63]  == findScaleFactor, bitallocation.js:290-299
 __device__ __forceinline__ int scale_factor_index(float maxabs, TablesPtr T) {
   if (!(maxabs > 0.0f)) return 0;
@@ -567,6 +578,7 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
 
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
+  if (lane < 12) S.sfi[52 + lane] = 0;   // modes byte (all long) and padding of the side record
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   __syncthreads();
 
@@ -704,17 +716,20 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
       dst[lane] = src[lane];
       dst[64 + lane] = src[64 + lane];
     }
-    if (lane < 52 && !(L.debug & 64)) {
-      const int start = kStartLong[lane];
-      const int n = kSpecs[lane];
+    {
+      // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
+      // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
+      const bool wide = lane >= 44;
+      const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
+      const int half = wide ? (lane & 1) : 0;
+      const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
+      const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
       float mx = 0.0f;
-      for (int j = 0; j < n; j++) {
-        const float a = fabsf(coef[start + j]);
-        if (a > mx) mx = a;
-      }
-      S.sfi[lane] = (uint8_t)scale_factor_index(mx, T);
-    } else {
-      S.sfi[lane] = 0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
+      mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
+      const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+      if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
     }
     __syncthreads();
     if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
