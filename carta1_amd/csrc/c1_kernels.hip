@@ -115,7 +115,7 @@ __device__ __forceinline__ void qmf_analysis_core(const double *w, int lane, Tab
 }
 // Synthesis (qmf.js:89-102): out[2i+1] = sum_j work[2i+2j]*EVEN[j], out[2i] = sum_j work[2i+2j+1]*ODD[j].
 // Same window; pair u feeds tap j = u-d, walking u upwards.
-template <int D>
+template <int D, int S = 5>
 __device__ __forceinline__ void qmf_synthesis_core(const double *w, int lane, TablesPtr T,
                                                    double (&s0)[D], double (&s1)[D]) {
   const int base = 2 * D * lane;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void qmf_synthesis_core(const double *w, int lane, Ta
   for (int d = 0; d < D; d++) s0[d] = s1[d] = 0.0;
 #pragma unroll
   for (int u = 0; u <= 22 + D; ++u) {
-    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx(base + 2 * u)]);
+    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx<S>(base + 2 * u)]);
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int j = u - d;
@@ -1164,7 +1164,8 @@ struct alignas(16) DecodeLds {
   float band[512];
   union alignas(16) {
     struct { float re[256]; float im[256]; float mid[512]; } m;   // IMDCT
-    struct { alignas(16) double w2[320]; alignas(16) double w1[592]; float high[256]; } q;   // QMF synthesis
+    struct { alignas(16) double w2[454]; } q2;                   // stage-2 synthesis work buffer (padded 2 per 4)
+    struct { alignas(16) double w1[698]; } q1;                   // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
   } u;
 };
 
@@ -1178,12 +1179,12 @@ __device__ __forceinline__ uint32_t get_bits_be(const uint32_t *words, int pos, 
   return (uint32_t)((two >> (64 - o - nb)) & ((1ull << nb) - 1ull));
 }
 
-__global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   __shared__ DecodeLds S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFrames;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesDecode;
   float *__restrict__ pcm = L.pcm[ch];
 
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
   if (lane < 3) S.words[53 + lane] = 0u;
   __syncthreads();
 
-  const int64_t f_end = (f0 + kRunFrames < L.frames) ? f0 + kRunFrames : L.frames;
+  const int64_t f_end = (f0 + kRunFramesDecode < L.frames) ? f0 + kRunFramesDecode : L.frames;
   for (int64_t f = f0 - 1; f < f_end; ++f) {
     if (f < -(int64_t)L.halo_units) continue;
     const bool emit = f >= f0;
@@ -1329,52 +1330,51 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
     __syncthreads();
 
     // ---------------- qmfSynthesisStage (decoder.js:349-389) ----------------
-    double *w2 = S.u.q.w2, *w1 = S.u.q.w1;
-    float *high = S.u.q.high;
-    {
-      // high band delay compensation (:360-366)
+    double *w2 = S.u.q2.w2, *w1 = S.u.q1.w1;
+    // high band delay compensation (:360-366): delayed high sample j = j < 39 ? previous tail : band2[j-39]
+    float hi4[4];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const int i = lane + 64 * m;
-        high[i] = i < 39 ? S.dhi[i] : S.band[256 + i - 39];
-      }
+    for (int t = 0; t < 4; t++) {
+      const int j = 4 * lane + t;
+      hi4[t] = j < 39 ? S.dhi[j] : S.band[256 + j - 39];
+    }
+    {
       float keep = 0.0f;
       if (lane < 39) keep = S.band[256 + 217 + lane];
       // stage 2: low + mid -> 256 samples (qmf.js:78-84 interleave)
-      if (lane < 46) w2[pidx(lane)] = S.d2[lane];
+      if (lane < 46) w2[pidx<2>(lane)] = S.d2[lane];
 #pragma unroll
       for (int d = 0; d < 2; d++) {
         const int i = 2 * lane + d;
         const double l = S.band[i], h = S.band[128 + i];
-        w2[pidx(46 + 2 * i)] = (double)f32(0.5 * (l + h));
-        w2[pidx(46 + 2 * i + 1)] = (double)f32(0.5 * (l - h));
+        *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 2 * i)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
       }
       __syncthreads();
       if (lane < 39) S.dhi[lane] = keep;
     }
     {
       double s0[2], s1[2];
-      qmf_synthesis_core<2>(w2, lane, T, s0, s1);
-      if (lane < 46) { S.d2[lane] = w2[pidx(256 + lane)]; w1[pidx(lane)] = S.d1[lane]; }
-      // stage 1 input: (stage-2 output, delayed high); stage-2 output i pair: out[2i] = s1, out[2i+1] = s0
+      qmf_synthesis_core<2, 2>(w2, lane, T, s0, s1);
+      if (lane < 46) S.d2[lane] = w2[pidx<2>(256 + lane)];
+      __syncthreads();                                    // w1 reuses the memory of w2 from here on
+      if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
+      // stage 1 input: (stage-2 output, delayed high); stage-2 output pair of i: out[2i] = s1, out[2i+1] = s0
 #pragma unroll
       for (int d = 0; d < 2; d++) {
-        const int i = 2 * lane + d;                       // stage-2 convolution index; produces samples 2i, 2i+1
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-          const int sidx = 2 * i + t;                     // sample index in the 256-sample low band
+          const int sidx = 4 * lane + 2 * d + t;          // sample index in the 256-sample low band
           const double l = (double)f32(t == 0 ? s1[d] : s0[d]);
-          const double h = high[sidx];
-          w1[pidx(46 + 2 * sidx)] = (double)f32(0.5 * (l + h));
-          w1[pidx(46 + 2 * sidx + 1)] = (double)f32(0.5 * (l - h));
+          const double h = hi4[2 * d + t];
+          *reinterpret_cast<double2 *>(&w1[pidx<3>(46 + 2 * sidx)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
         }
       }
     }
     __syncthreads();
     {
       double s0[4], s1[4];
-      qmf_synthesis_core<4>(w1, lane, T, s0, s1);
-      if (lane < 46) S.d1[lane] = w1[pidx(512 + lane)];
+      qmf_synthesis_core<4, 3>(w1, lane, T, s0, s1);
+      if (lane < 46) S.d1[lane] = w1[pidx<3>(512 + lane)];
       if (emit) {
         float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512 + 8 * lane);
         dst[0] = make_float4(f32(s1[0]), f32(s0[0]), f32(s1[1]), f32(s0[1]));
@@ -1450,7 +1450,7 @@ void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream) {
   hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), dim3(C1_WAVE * kPackWaves), 0, stream, L);
 }
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFrames - 1) / kRunFrames;
+  const int64_t runs = (L.frames + kRunFramesDecode - 1) / kRunFramesDecode;
   hipLaunchKernelGGL(k_decode, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
 }
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream) {
