@@ -94,15 +94,22 @@ __device__ __forceinline__ int pidx(int e) { return e + ((e >> S) << 1); }
 // A lane owns D consecutive outputs i = D*lane+d, i.e. the 46+2D doubles from 2*D*lane, read
 // as 16-byte (even,odd) pairs u = 22+D .. 0; pair u feeds tap j = d+23-u of output d, so walking
 // u downwards adds the terms of every sum in the reference's order.
+// When 2D == 2^S (4 outputs per lane with S = 3, 2 with S = 2) the padded index of a lane's window is
+// affine in the lane: pidx<S>(2D*lane + 2u) = (2D+2)*lane + 2u + 2*((2u) >> S), so every read is
+// "lane base + compile-time offset" and costs no address arithmetic.
+template <int D, int S>
+__device__ __forceinline__ const double2 *qmf_window(const double *w, int lane, int u) {
+  if constexpr (2 * D == (1 << S)) return reinterpret_cast<const double2 *>(w + (2 * D + 2) * lane + (2 * u + 2 * ((2 * u) >> S)));
+  else return reinterpret_cast<const double2 *>(&w[pidx<S>(2 * D * lane + 2 * u)]);
+}
 template <int D, int S = 5>
 __device__ __forceinline__ void qmf_analysis_core(const double *w, int lane, TablesPtr T,
                                                   double (&even)[D], double (&odd)[D]) {
-  const int base = 2 * D * lane;
 #pragma unroll
   for (int d = 0; d < D; d++) even[d] = odd[d] = 0.0;
 #pragma unroll
   for (int u = 22 + D; u >= 0; --u) {
-    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx<S>(base + 2 * u)]);
+    const double2 x = *qmf_window<D, S>(w, lane, u);
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int j = d + 23 - u;
@@ -118,12 +125,11 @@ __device__ __forceinline__ void qmf_analysis_core(const double *w, int lane, Tab
 template <int D, int S = 5>
 __device__ __forceinline__ void qmf_synthesis_core(const double *w, int lane, TablesPtr T,
                                                    double (&s0)[D], double (&s1)[D]) {
-  const int base = 2 * D * lane;
 #pragma unroll
   for (int d = 0; d < D; d++) s0[d] = s1[d] = 0.0;
 #pragma unroll
   for (int u = 0; u <= 22 + D; ++u) {
-    const double2 x = *reinterpret_cast<const double2 *>(&w[pidx<S>(base + 2 * u)]);
+    const double2 x = *qmf_window<D, S>(w, lane, u);
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int j = u - d;
