@@ -531,11 +531,17 @@ struct alignas(16) LongLds {
 };
 
 // one radix-2 butterfly (fft.js:46-60) on interleaved points; H = half stride (compile time)
+// (e = index of the even point, tw = index of the twiddle: both depend on the lane only and are
+// computed once per wave by butterfly_geometry)
 template <int H>
-__device__ __forceinline__ void fft_butterfly(float2 *z, int t, TablesPtr T) {
+__device__ __forceinline__ void butterfly_geometry(int t, int &e, int &tw) {
   const int k = t & (H - 1);
-  const int e = ((t - k) << 1) + k;
-  const double tr = T->fft_tw[H - 1 + k][0], ti = T->fft_tw[H - 1 + k][1];
+  e = ((t - k) << 1) + k;
+  tw = H - 1 + k;
+}
+template <int H>
+__device__ __forceinline__ void fft_butterfly(float2 *z, int e, int tw, TablesPtr T) {
+  const double tr = T->fft_tw[tw][0], ti = T->fft_tw[tw][1];
   const float2 ze = z[e], zo = z[e + H];
   const double er = ze.x, ei = ze.y, orr = zo.x, oi = zo.y;
   const double xr = orr * tr - oi * ti;
@@ -545,20 +551,31 @@ __device__ __forceinline__ void fft_butterfly(float2 *z, int t, TablesPtr T) {
 }
 
 // pre-twiddle of complex point k of an N-point MDCT (mdct.js:76-105), N4 = N/4, written bit-reversed
+// The five indices and the sign mask depend on the lane only: PreGeometry is filled once per wave.
+struct PreGeometry { int ia, ib, ic, id, zi; uint32_t sign; };
 template <int N4, int LG>
-__device__ __forceinline__ void mdct_pre(const float *in, const __attribute__((address_space(4))) double *tab, int k,
-                                         float2 *z) {
+__device__ __forceinline__ PreGeometry pre_geometry(int k) {
   const int i = 2 * k;
   const bool lo = i < N4;
-  const float a = in[3 * N4 - 1 - i];
-  const float c = in[N4 + i];
-  const uint32_t sign = lo ? 0u : 0x80000000u;       // second half: r = a - b, m = c + d
-  const float b = __uint_as_float(__float_as_uint(in[lo ? 3 * N4 + i : i - N4]) ^ sign);
-  const float d = __uint_as_float(__float_as_uint(in[lo ? N4 - 1 - i : 5 * N4 - 1 - i]) ^ sign);
+  PreGeometry g;
+  g.ia = 3 * N4 - 1 - i;
+  g.ic = N4 + i;
+  g.ib = lo ? 3 * N4 + i : i - N4;
+  g.id = lo ? N4 - 1 - i : 5 * N4 - 1 - i;
+  g.sign = lo ? 0u : 0x80000000u;       // second half: r = a - b, m = c + d
+  g.zi = bitrev(k, LG);
+  return g;
+}
+__device__ __forceinline__ void mdct_pre(const float *in, const __attribute__((address_space(4))) double *tab, int i,
+                                         const PreGeometry &g, float2 *z) {
+  const float a = in[g.ia];
+  const float c = in[g.ic];
+  const float b = __uint_as_float(__float_as_uint(in[g.ib]) ^ g.sign);
+  const float d = __uint_as_float(__float_as_uint(in[g.id]) ^ g.sign);
   const double r = (double)a + (double)b;
   const double mm = (double)c - (double)d;
   const double cs = tab[i], sn = tab[i + 1];
-  z[bitrev(k, LG)] = make_float2(f32(r * cs + mm * sn), f32(mm * cs - r * sn));
+  z[g.zi] = make_float2(f32(r * cs + mm * sn), f32(mm * cs - r * sn));
 }
 
 // post-twiddle (mdct.js:110-119) of point i; REV = spectrum reversal of bands 1,2 (utils.js:42-48)
@@ -586,6 +603,12 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
   if (lane < 12) S.sfi[52 + lane] = 0;   // modes byte (all long) and padding of the side record
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
+  // lane-only geometry of the MDCT core, computed once (everything else is re-derived per frame)
+  const PreGeometry g256 = pre_geometry<64, 6>(lane0), g512a = pre_geometry<128, 7>(lane0), g512b = pre_geometry<128, 7>(lane0 + 64);
+  int fe1, fe2, fe4, fe8, fe16, fe32, fe64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
+  butterfly_geometry<1>(lane0, fe1, ft1); butterfly_geometry<2>(lane0, fe2, ft2); butterfly_geometry<4>(lane0, fe4, ft4);
+  butterfly_geometry<8>(lane0, fe8, ft8); butterfly_geometry<16>(lane0, fe16, ft16); butterfly_geometry<32>(lane0, fe32, ft32);
+  butterfly_geometry<64>(lane0, fe64, ft64);
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
@@ -689,21 +712,21 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
     __syncthreads();
     float2 *z = S.u.m.z;
     if (!(L.debug & 32)) {
-    mdct_pre<64, 6>(in0, T->mdct_fwd256, lane, z);
-    mdct_pre<64, 6>(in1, T->mdct_fwd256, lane, z + 64);
-    mdct_pre<128, 7>(in2, T->mdct_fwd512, lane, z + 128);
-    mdct_pre<128, 7>(in2, T->mdct_fwd512, lane + 64, z + 128);
+    mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256, z);
+    mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256, z + 64);
+    mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
+    mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
     }
     __syncthreads();
     // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
     if (!(L.debug & 8)) {
-    fft_butterfly<1>(z, lane, T); fft_butterfly<1>(z + 128, lane, T); __syncthreads();
-    fft_butterfly<2>(z, lane, T); fft_butterfly<2>(z + 128, lane, T); __syncthreads();
-    fft_butterfly<4>(z, lane, T); fft_butterfly<4>(z + 128, lane, T); __syncthreads();
-    fft_butterfly<8>(z, lane, T); fft_butterfly<8>(z + 128, lane, T); __syncthreads();
-    fft_butterfly<16>(z, lane, T); fft_butterfly<16>(z + 128, lane, T); __syncthreads();
-    fft_butterfly<32>(z, lane, T); fft_butterfly<32>(z + 128, lane, T); __syncthreads();
-    fft_butterfly<64>(z + 128, lane, T); __syncthreads();
+    fft_butterfly<1>(z, fe1, ft1, T); fft_butterfly<1>(z + 128, fe1, ft1, T); __syncthreads();
+    fft_butterfly<2>(z, fe2, ft2, T); fft_butterfly<2>(z + 128, fe2, ft2, T); __syncthreads();
+    fft_butterfly<4>(z, fe4, ft4, T); fft_butterfly<4>(z + 128, fe4, ft4, T); __syncthreads();
+    fft_butterfly<8>(z, fe8, ft8, T); fft_butterfly<8>(z + 128, fe8, ft8, T); __syncthreads();
+    fft_butterfly<16>(z, fe16, ft16, T); fft_butterfly<16>(z + 128, fe16, ft16, T); __syncthreads();
+    fft_butterfly<32>(z, fe32, ft32, T); fft_butterfly<32>(z + 128, fe32, ft32, T); __syncthreads();
+    fft_butterfly<64>(z + 128, fe64, ft64, T); __syncthreads();
     }
     float *coef = S.u.m.a.c.coef;
     if (!(L.debug & 32)) {
