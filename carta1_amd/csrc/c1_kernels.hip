@@ -531,30 +531,42 @@ struct alignas(16) LongLds {
 };
 
 // one radix-2 butterfly (fft.js:46-60) on interleaved points; H = half stride (compile time)
-// (e = index of the even point, tw = index of the twiddle: both depend on the lane only and are
-// computed once per wave by butterfly_geometry)
+// Where logical point j (0..127) of a 128-point region lives in LDS: a GF(2)-linear permutation found by
+// search (tools/lds_model.py) that makes the bit-reversed pre-twiddle stores, all seven butterfly stages
+// and the post-twiddle loads close to bank-conflict free (model cost 188 vs 364 for the identity).
+// Indices depend on the lane only and are computed once per wave, so the swizzle costs nothing per frame.
+__device__ __forceinline__ int zsw(int j) {
+  constexpr int rows[7] = {35, 70, 12, 88, 112, 32, 71};
+  int o = 0;
+#pragma unroll
+  for (int r = 0; r < 7; r++) o |= (__popc(rows[r] & j) & 1) << r;
+  return o;
+}
+// (pe/po = LDS slots of the even/odd point, tw = index of the twiddle: lane-only, see butterfly_geometry)
 template <int H>
-__device__ __forceinline__ void butterfly_geometry(int t, int &e, int &tw) {
+__device__ __forceinline__ void butterfly_geometry(int t, int &pe, int &po, int &tw) {
   const int k = t & (H - 1);
-  e = ((t - k) << 1) + k;
+  const int e = ((t - k) << 1) + k;
+  pe = zsw(e);
+  po = zsw(e + H);
   tw = H - 1 + k;
 }
 template <int H>
-__device__ __forceinline__ void fft_butterfly(float2 *z, int e, int tw, TablesPtr T) {
+__device__ __forceinline__ void fft_butterfly(float2 *z, int pe, int po, int tw, TablesPtr T) {
   const double tr = T->fft_tw[tw][0], ti = T->fft_tw[tw][1];
-  const float2 ze = z[e], zo = z[e + H];
+  const float2 ze = z[pe], zo = z[po];
   const double er = ze.x, ei = ze.y, orr = zo.x, oi = zo.y;
   const double xr = orr * tr - oi * ti;
   const double xi = orr * ti + oi * tr;
-  z[e] = make_float2(f32(er + xr), f32(ei + xi));
-  z[e + H] = make_float2(f32(er - xr), f32(ei - xi));
+  z[pe] = make_float2(f32(er + xr), f32(ei + xi));
+  z[po] = make_float2(f32(er - xr), f32(ei - xi));
 }
 
 // pre-twiddle of complex point k of an N-point MDCT (mdct.js:76-105), N4 = N/4, written bit-reversed
 // The five indices and the sign mask depend on the lane only: PreGeometry is filled once per wave.
 struct PreGeometry { int ia, ib, ic, id, zi; uint32_t sign; };
 template <int N4, int LG>
-__device__ __forceinline__ PreGeometry pre_geometry(int k) {
+__device__ __forceinline__ PreGeometry pre_geometry(int k, int region_offset) {
   const int i = 2 * k;
   const bool lo = i < N4;
   PreGeometry g;
@@ -563,7 +575,7 @@ __device__ __forceinline__ PreGeometry pre_geometry(int k) {
   g.ib = lo ? 3 * N4 + i : i - N4;
   g.id = lo ? N4 - 1 - i : 5 * N4 - 1 - i;
   g.sign = lo ? 0u : 0x80000000u;       // second half: r = a - b, m = c + d
-  g.zi = bitrev(k, LG);
+  g.zi = zsw(region_offset + bitrev(k, LG));
   return g;
 }
 __device__ __forceinline__ void mdct_pre(const float *in, const __attribute__((address_space(4))) double *tab, int i,
@@ -580,9 +592,9 @@ __device__ __forceinline__ void mdct_pre(const float *in, const __attribute__((a
 
 // post-twiddle (mdct.js:110-119) of point i; REV = spectrum reversal of bands 1,2 (utils.js:42-48)
 template <int NFFT, bool REV>
-__device__ __forceinline__ void mdct_post(const float2 *z, const __attribute__((address_space(4))) double *tab, int i,
+__device__ __forceinline__ void mdct_post(const float2 *z, int slot, const __attribute__((address_space(4))) double *tab, int i,
                                           float *dst) {
-  const float2 zz = z[i];
+  const float2 zz = z[slot];
   const double cs = tab[2 * i], sn = tab[2 * i + 1], rr = zz.x, ii = zz.y;
   const float o0 = f32(-rr * cs - ii * sn);
   const float o1 = f32(-rr * sn + ii * cs);
@@ -604,11 +616,13 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
   if (lane < 12) S.sfi[52 + lane] = 0;   // modes byte (all long) and padding of the side record
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   // lane-only geometry of the MDCT core, computed once (everything else is re-derived per frame)
-  const PreGeometry g256 = pre_geometry<64, 6>(lane0), g512a = pre_geometry<128, 7>(lane0), g512b = pre_geometry<128, 7>(lane0 + 64);
-  int fe1, fe2, fe4, fe8, fe16, fe32, fe64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
-  butterfly_geometry<1>(lane0, fe1, ft1); butterfly_geometry<2>(lane0, fe2, ft2); butterfly_geometry<4>(lane0, fe4, ft4);
-  butterfly_geometry<8>(lane0, fe8, ft8); butterfly_geometry<16>(lane0, fe16, ft16); butterfly_geometry<32>(lane0, fe32, ft32);
-  butterfly_geometry<64>(lane0, fe64, ft64);
+  const PreGeometry g256a = pre_geometry<64, 6>(lane0, 0), g256b = pre_geometry<64, 6>(lane0, 64);
+  const PreGeometry g512a = pre_geometry<128, 7>(lane0, 0), g512b = pre_geometry<128, 7>(lane0 + 64, 0);
+  int fe1, fe2, fe4, fe8, fe16, fe32, fe64, fo1, fo2, fo4, fo8, fo16, fo32, fo64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
+  butterfly_geometry<1>(lane0, fe1, fo1, ft1); butterfly_geometry<2>(lane0, fe2, fo2, ft2); butterfly_geometry<4>(lane0, fe4, fo4, ft4);
+  butterfly_geometry<8>(lane0, fe8, fo8, ft8); butterfly_geometry<16>(lane0, fe16, fo16, ft16); butterfly_geometry<32>(lane0, fe32, fo32, ft32);
+  butterfly_geometry<64>(lane0, fe64, fo64, ft64);
+  const int ps0 = zsw(lane0), ps1 = zsw(64 + lane0);     // post-twiddle slots of points lane and lane+64
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
@@ -712,28 +726,28 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
     __syncthreads();
     float2 *z = S.u.m.z;
     if (!(L.debug & 32)) {
-    mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256, z);
-    mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256, z + 64);
+    mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256a, z);
+    mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256b, z);
     mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
     mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
     }
     __syncthreads();
     // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
     if (!(L.debug & 8)) {
-    fft_butterfly<1>(z, fe1, ft1, T); fft_butterfly<1>(z + 128, fe1, ft1, T); __syncthreads();
-    fft_butterfly<2>(z, fe2, ft2, T); fft_butterfly<2>(z + 128, fe2, ft2, T); __syncthreads();
-    fft_butterfly<4>(z, fe4, ft4, T); fft_butterfly<4>(z + 128, fe4, ft4, T); __syncthreads();
-    fft_butterfly<8>(z, fe8, ft8, T); fft_butterfly<8>(z + 128, fe8, ft8, T); __syncthreads();
-    fft_butterfly<16>(z, fe16, ft16, T); fft_butterfly<16>(z + 128, fe16, ft16, T); __syncthreads();
-    fft_butterfly<32>(z, fe32, ft32, T); fft_butterfly<32>(z + 128, fe32, ft32, T); __syncthreads();
-    fft_butterfly<64>(z + 128, fe64, ft64, T); __syncthreads();
+    fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
+    fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
+    fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
+    fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
+    fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
+    fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
+    fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
     }
     float *coef = S.u.m.a.c.coef;
     if (!(L.debug & 32)) {
-    mdct_post<64, false>(z, T->mdct_fwd256, lane, coef);
-    mdct_post<64, true>(z + 64, T->mdct_fwd256, lane, coef + 128);
-    mdct_post<128, true>(z + 128, T->mdct_fwd512, lane, coef + 256);
-    mdct_post<128, true>(z + 128, T->mdct_fwd512, lane + 64, coef + 256);
+    mdct_post<64, false>(z, ps0, T->mdct_fwd256, lane, coef);
+    mdct_post<64, true>(z, ps1, T->mdct_fwd256, lane, coef + 128);
+    mdct_post<128, true>(z + 128, ps0, T->mdct_fwd512, lane, coef + 256);
+    mdct_post<128, true>(z + 128, ps1, T->mdct_fwd512, lane + 64, coef + 256);
     }
     __syncthreads();
 
