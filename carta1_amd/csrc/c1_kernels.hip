@@ -1081,37 +1081,89 @@ struct PackLds {
 // order), quantizes them (quantization.js:34-56) and appends the mantissas MSB-first to a 64-bit
 // accumulator (serialization.js:79-91).  Completed 32-bit groups that lie wholly inside the lane's bit
 // range are plain LDS stores; only the first and last, which neighbours share, are atomic ORs.
+// The loop is software pipelined: the allocation/side records of the unit two steps ahead and the
+// coefficients of the next unit are in flight while the current unit is packed.
+struct PackHeader {   // what a lane needs of one unit's allocation and side records
+  uint32_t al_wl;     // allocation dword holding this lane's word-length nibble        (al[lane >> 3])
+  uint32_t al7;       // last allocation dword: amount index, fallback flag
+  uint32_t sd_sf;     // side dword holding this lane's scale-factor index              (side[lane >> 2])
+  uint32_t sd_q;      // side dword lane & 15 (four scale factors for the 24-bit field, modes in dword 13)
+  uint32_t al_a, al_b;   // allocation dwords (lane - 1) & 7 and lane & 7 (word-length bytes, lanes 0..7)
+};
+__device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, int64_t unit, int lane) {
+  const uint32_t *al = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes);
+  const uint32_t *side = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes);
+  PackHeader h;
+  h.al_wl = al[lane >> 3];
+  h.al7 = al[7];
+  h.sd_sf = side[lane >> 2];
+  h.sd_q = side[lane & 15];
+  h.al_a = al[(lane + 7) & 7];
+  h.al_b = al[lane & 7];
+  return h;
+}
+
 __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L) {
   __shared__ PackLds lds[kPackWaves];
+  __shared__ double norm_s[64 * 16];        // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
   TablesPtr T = C1_TABLES(L.tables);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   PackLds &S = lds[wave];
-  // which BFU / which coefficient inside it each of this lane's 8 slots is: unit-invariant
-  int slot_b[8], slot_j[8];
+  for (int i = threadIdx.x; i < 64 * 16; i += C1_WAVE * kPackWaves) norm_s[i] = T->norm[i];
+  __syncthreads();
+  // which BFU / which coefficient each of this lane's 8 slots is, and where it sits for long / short blocks
+  int slot_b[8], slot_j[8], at_long[8], at_short[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     const int p = 8 * lane + m;
     slot_b[m] = bfu_of_slot(p);
     slot_j[m] = p - kBfuFirst[slot_b[m]];
+    at_long[m] = kStartLong[slot_b[m]] + slot_j[m];
+    at_short[m] = kStartShort[slot_b[m]] + slot_j[m];
   }
   const int my_size = lane < 52 ? kSpecs[lane] : 0;
+  const int my_long = lane < 52 ? kStartLong[lane] : 0, my_short = lane < 52 ? kStartShort[lane] : 0;
   const int64_t units_total = L.frames * L.channels;
-  for (int64_t unit_v = (int64_t)blockIdx.x * kPackWaves + wave; unit_v < units_total; unit_v += (int64_t)gridDim.x * kPackWaves) {
-    const int64_t unit = ((int64_t)__builtin_amdgcn_readfirstlane((int)(unit_v >> 32)) << 32) |
-                         (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_v);     // wave-uniform: scalar loads below
-    const uint32_t *al = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes);
-    const uint32_t *side = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes);
-    const uint32_t a7 = al[7];
+  const int64_t stride = (int64_t)gridDim.x * kPackWaves;
+  const int64_t u_first = (int64_t)blockIdx.x * kPackWaves + wave;
+  auto load_coefs = [&](int64_t unit, uint32_t modes_dword, float (&x)[8]) {
+    const float *coefs = L.coefs + (unit << 9);
+    const int modes = (int)(modes_dword & 0xff);
+    if (modes == 0) {   // all long: coefficient order == slot order
+      const float4 a = reinterpret_cast<const float4 *>(coefs)[2 * lane], c = reinterpret_cast<const float4 *>(coefs)[2 * lane + 1];
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+    } else {
+      const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int mode = slot_b[m] >= 36 ? m2 : (slot_b[m] >= 20 ? m1 : m0);
+        x[m] = coefs[mode == 0 ? at_long[m] : at_short[m]];
+      }
+    }
+  };
+  if (u_first >= units_total) return;
+  PackHeader h0 = pack_load_header(L, u_first, lane);
+  PackHeader h1 = pack_load_header(L, u_first + stride < units_total ? u_first + stride : u_first, lane);
+  float x[8];
+  load_coefs(u_first, __shfl(h0.sd_q, 13), x);
+  for (int64_t unit = u_first; unit < units_total; unit += stride) {
+    // ---- issue the loads of the units ahead ----
+    const int64_t u1 = unit + stride, u2 = unit + 2 * stride;
+    PackHeader h2 = pack_load_header(L, u2 < units_total ? u2 : unit, lane);
+    float xn[8];
+    load_coefs(u1 < units_total ? u1 : unit, __shfl(h1.sd_q, 13), xn);
+    // ---- this unit ----
+    const uint32_t a7 = h0.al7;
     const bool fallback = (a7 >> 27) & 1;
     const int amount = (int)(a7 >> 28) & 7;
     const int n = kAmounts[amount];
-    const int modes = (int)(side[13] & 0xff);
+    const int modes = (int)(__shfl(h0.sd_q, 13) & 0xff);
     const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
     if (lane < 56) S.words[lane] = 0;
-    int wl = 0, s = 0;
+    int wl = 0, sf = 0;
     if (lane < 52) {
-      wl = lane < n ? (int)((al[lane >> 3] >> ((lane & 7) * 4)) & 15) : 0;
-      s = fallback ? 0 : (int)((side[lane >> 2] >> ((lane & 3) * 8)) & 63);
+      wl = lane < n ? (int)((h0.al_wl >> ((lane & 7) * 4)) & 15) : 0;
+      sf = fallback ? 0 : (int)((h0.sd_sf >> ((lane & 3) * 8)) & 63);
     }
     // bit offset of every BFU's mantissas: exclusive prefix sum of bits*size over the wave
     const int bits_b = wl_bits(wl);
@@ -1124,38 +1176,26 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L)
     }
     if (lane < 52) {
       const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
-      S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)bfu_start(lane, mode) << 16);
-      S.normd[lane] = (s != 0 && bits_b != 0) ? T->norm[s * 16 + wl] : 0.0;
+      S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
+      S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
     }
     wave_sync();
     // header (serialization.js:46-53) and word-length indices (:55-64): the 4-bit indices are already
     // packed two per byte in the allocation record, low nibble first; the unit wants the high nibble first
     if (lane < 8) {
-      auto wl_be = [&](int q) -> uint32_t {           // word-length bytes 4q..4q+3 as a big-endian word
-        if (q < 0 || q > 6) return 0u;
-        const uint32_t x = al[q];
-        return __builtin_bswap32(((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu));
-      };
+      auto wl_be = [](uint32_t v) -> uint32_t { return __builtin_bswap32(((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu)); };
       const uint32_t header = ((uint32_t)(2 - m0) << 14) | ((uint32_t)(2 - m1) << 12) | ((uint32_t)(3 - m2) << 10) | ((uint32_t)amount << 5);
-      const uint32_t prev = lane == 0 ? (header & 0xffffu) : wl_be(lane - 1);
-      atomicOr(&S.words[lane], (prev << 16) | (wl_be(lane) >> 16));
+      const uint32_t prev = lane == 0 ? (header & 0xffffu) : wl_be(h0.al_a);      // word-length bytes 4(lane-1)..
+      const uint32_t cur = lane == 7 ? 0u : wl_be(h0.al_b);                       // last dword carries flags, no indices
+      atomicOr(&S.words[lane], (prev << 16) | (cur >> 16));
     }
     // scale-factor indices (:66-77): four 6-bit fields = 24 bits per lane
     if (lane < (n >> 2)) {
-      const uint32_t q = fallback ? 0u : side[lane];
+      const uint32_t q = fallback ? 0u : h0.sd_q;
       const uint32_t t = ((q & 63u) << 18) | (((q >> 8) & 63u) << 12) | (((q >> 16) & 63u) << 6) | ((q >> 24) & 63u);
       put_bits_be(S.words, 16 + 4 * n + 24 * lane, t, 24);
     }
     // mantissas
-    const float *coefs = L.coefs + (unit << 9);
-    float x[8];
-    if (modes == 0) {   // all long: coefficient order == slot order
-      const float4 a = reinterpret_cast<const float4 *>(coefs)[2 * lane], c = reinterpret_cast<const float4 *>(coefs)[2 * lane + 1];
-      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
-    } else {
-#pragma unroll
-      for (int m = 0; m < 8; m++) x[m] = coefs[(S.desc[slot_b[m]] >> 16) + slot_j[m]];
-    }
     uint64_t acc = 0;
     int cnt = -1, wi = 0;
     bool first = true;
@@ -1189,6 +1229,9 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L)
     wave_sync();
     if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
     wave_sync();
+    h0 = h1; h1 = h2;
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[m] = xn[m];
   }
 }
 
