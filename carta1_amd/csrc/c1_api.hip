@@ -161,6 +161,31 @@ int build_encode_opts(const c1_encode_options &o, C1DevEncOpts *d) {
       const auto it = std::lower_bound(uniq.begin(), uniq.end(), pri[s * 15 + wl]);
       d->rank[s * 16 + wl] = (uint16_t)(1 + (it - uniq.begin()));
     }
+  // Is the order of the ranks the order of an integer form?  (bias 1: priority = 2^(s/3-21) * {0.875 | 2^-(wl+2)}
+  // -> 2s-1 for wl = 0 and 2s - 6wl - 12 for wl >= 1.)  Search small coefficients; ties must match too.
+  d->rank_affine = 0;
+  {
+    std::vector<int> order;                       // (s, wl) pairs sorted by rank
+    for (int s = 1; s < 64; s++)
+      for (int wl = 0; wl < 15; wl++) order.push_back(s * 16 + wl);
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return d->rank[x] < d->rank[y]; });
+    for (int A = 1; A <= 12 && !d->rank_affine; A++)
+      for (int B = 1; B <= 36 && !d->rank_affine; B++)
+        for (int C = -2 * B; C <= 0 && !d->rank_affine; C++) {
+          auto key = [&](int idx) { const int s = idx >> 4, wl = idx & 15; return wl == 0 ? A * s + C : A * s - B * wl - B; };
+          bool ok = true;
+          int lo = key(order[0]), hi = lo;
+          for (size_t i = 1; i < order.size() && ok; i++) {
+            const int k0 = key(order[i - 1]), k1 = key(order[i]);
+            const bool req = d->rank[order[i]] == d->rank[order[i - 1]];
+            if (req ? (k1 != k0) : !(k1 > k0)) ok = false;
+            lo = std::min(lo, k1); hi = std::max(hi, k1);
+          }
+          if (ok && hi - lo + 1 < 1023) {
+            d->rank_affine = 1; d->rank_a = A; d->rank_b = B; d->rank_c = C; d->rank_off = 1 - lo;
+          }
+        }
+  }
   return C1_OK;
 }
 
@@ -227,7 +252,7 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
   if (units <= ctx->ws_units) return C1_OK;
   HIP_TRY(hipDeviceSynchronize());
   free_workspace(ctx);
-  for (int p = 0; p < 2; p++) {
+  for (int p = 0; p < (ctx->pipeline ? 2 : 1); p++) {
     HIP_TRY(hipMalloc(&ctx->d_coefs[p], (size_t)units * 512 * sizeof(float)));
     HIP_TRY(hipMalloc(&ctx->d_side[p], (size_t)units * kSideBytes));
     HIP_TRY(hipMalloc(&ctx->d_alloc[p], (size_t)units * kAllocBytes));
@@ -510,7 +535,7 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
     ctx->pipeline = pl ? atoi(pl) != 0 : false;   // measured: no gain while one kernel's grid already owns every CU's LDS
   }
   const char *env = getenv("C1_CHUNK_FRAMES");
-  ctx->chunk_frames = env ? atoll(env) : 131072;
+  ctx->chunk_frames = env ? atoll(env) : 524288;
   if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
   *out = ctx;
   return C1_OK;

@@ -36,6 +36,10 @@ struct C1DevEncOpts {
   int32_t modes[3];          // fixed modes or -1
   int32_t pad_;
   uint16_t rank[64 * 16];    // rank (1..960) of the Float32 heap priority of (sfi, wl); 0 = unused
+  // when the rank order is the order of an integer form A*sfi - B*wl (wl >= 1) / A*sfi + C (wl == 0),
+  // as it is for the usual biases, the kernels compute it instead of reading the table
+  int32_t rank_affine, rank_a, rank_b, rank_c, rank_off;
+  int32_t pad2_[3];
 };
 
 // ---- geometry ------------------------------------------------------------------------------------

@@ -835,11 +835,19 @@ __device__ __forceinline__ void heap_sift_down(uint32_t *hp, int sentinel, int i
 
 // One greedy heap per lane: candidate with `n` BFUs.  sf = the unit's 52 scale-factor indices (13 dwords).
 // Returns the 52 final word-length indices (4 bits each) and the candidate's total distortion.
+// During the spending loop the three top slots of the heap live in registers (r0 = root, r1/r2 = its
+// children): most steps end at the root (equal priorities do not move, :325-331), so they touch no memory.
 __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_t (&sf)[13], const C1DevEncOpts *O,
                                               bool live, uint64_t &res0, uint64_t &res1, uint64_t &res2,
                                               uint64_t &res3, double &total) {
   const __attribute__((address_space(4))) uint16_t *rank_t = (const __attribute__((address_space(4))) uint16_t *)O->rank;
   const __attribute__((address_space(4))) double *biased = (const __attribute__((address_space(4))) double *)O->biased;
+  const bool affine = O->rank_affine != 0;
+  const int ka = O->rank_a, kb = O->rank_b, kc = O->rank_c, koff = O->rank_off;
+  auto rank_of = [&](int s, int wl) -> uint32_t {
+    if (affine) return (uint32_t)(ka * s + (wl == 0 ? kc : -kb * wl - kb) + koff);
+    return rank_t[s * 16 + (wl & 15)];
+  };
   int remaining = 212 * 8 - 40 - 10 * n;                   // bitallocation.js:97-100
   int hs = 0;
   // distributeBitsRDO (:203-281): initial heap = BFUs below n with a non-zero scale factor
@@ -847,7 +855,7 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
   for (int b = 0; b < 52; b++) {
     const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
     if (b < n && s != 0 && live) {
-      hp[hs * 64] = heap_entry(rank_t[s * 16], kSpecs[b], s, 0, b);
+      hp[hs * 64] = heap_entry(rank_of(s, 0), kSpecs[b], s, 0, b);
       hs++;
     }
   }
@@ -859,29 +867,56 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
   }
   // greedy spending loop (:244-278): the root either takes its next priority or leaves the heap (does not
   // fit :251-258, or reached the last word length :271-277); then one sift.
+  uint32_t r0 = hp[0], r1 = hp[64], r2 = hp[128];
   bool run = remaining > 0 && hs > 0;
   while (__builtin_amdgcn_ballot_w64(run) != 0) {
-    const uint32_t top = hp[0];
-    const uint32_t c1 = hp[64], c2 = hp[128];
-    const int wl = (top >> 6) & 15, size = (top >> 16) & 31;
+    const uint32_t top = r0;
+    const int wl = (top >> 6) & 15, size = (top >> 16) & 31, s = (top >> 10) & 63;
     const int cost = size << (wl == 0 ? 1 : 0);            // WORD_LENGTH_DELTA_BITS = [2,1,1,...]
     const bool fits = cost <= remaining;
     const int nxt = wl + (fits ? 1 : 0);
-    const bool leaves = !fits || nxt >= 15;
+    const bool leaves = run && (!fits || nxt >= 15);
     const uint32_t upd = (top & ~((0x3FFu << 21) | (15u << 6))) | ((uint32_t)nxt << 6);   // same BFU, new word length, rank 0
-    const uint32_t rk = rank_t[((top >> 6) & 0x3F0u) + (nxt & 15)];
-    const uint32_t last = hp[(hs > 0 ? hs - 1 : 0) * 64];
-    uint32_t v = leaves ? last : (upd | (rk << 21));
-    bool sift = false;
-    if (run) {
-      remaining -= fits ? cost : 0;
-      hs -= leaves ? 1 : 0;
-      if (leaves) hp[hs * 64] = upd;                       // parked in the freed slot with its final length
-      sift = hs > 0;
+    uint32_t v = upd | (rank_of(s, nxt) << 21);
+    if (__builtin_amdgcn_ballot_w64(leaves) != 0) {
+      // the last element replaces the root; the leaver is parked, rank 0, in the slot that frees
+      const int li = hs - 1;
+      const uint32_t deep = hp[(li > 3 ? li : 3) * 64];
+      const uint32_t last = li == 0 ? r0 : (li == 1 ? r1 : (li == 2 ? r2 : deep));
+      if (leaves) {
+        v = last;
+        hs = li;
+        if (li > 2) hp[li * 64] = upd;
+        r0 = li == 0 ? upd : r0; r1 = li == 1 ? upd : r1; r2 = li == 2 ? upd : r2;
+      }
     }
-    heap_sift_down(hp, 52, 0, v, c1, c2, sift);
+    if (run) remaining -= fits ? cost : 0;
+    const bool sift = run && hs > 0;
+    // level 0: root against r1, r2
+    const uint32_t vmax = v | kLow;
+    const bool tr0 = r2 > max(r1 | kLow, vmax);
+    const bool tl0 = !tr0 && r1 > vmax;
+    const bool mv0 = sift && (tr0 || tl0);
+    if (sift) r0 = mv0 ? (tr0 ? r2 : r1) : v;
+    if (__builtin_amdgcn_ballot_w64(mv0) != 0) {
+      // level 1: the chosen child's children are slots 3,4 or 5,6
+      const int i1 = tr0 ? 2 : 1;
+      const uint32_t *src = hp + (2 * i1 + 1) * 64;
+      const uint32_t el = src[0], er = src[64];
+      const bool tr1 = er > max(el | kLow, vmax);
+      const bool tl1 = !tr1 && el > vmax;
+      const bool mv1 = mv0 && (tr1 || tl1);
+      const uint32_t val = mv1 ? (tr1 ? er : el) : v;
+      if (mv0) { if (tr0) r2 = val; else r1 = val; }
+      if (__builtin_amdgcn_ballot_w64(mv1) != 0) {
+        const int i2 = 2 * i1 + 1 + (tr1 ? 1 : 0);
+        const uint32_t *s2 = hp + (2 * i2 + 1) * 64;     // i2 <= 6: children 7..14 always inside the lane's slots
+        heap_sift_down(hp, 52, i2, v, s2[0], s2[64], mv1);
+      }
+    }
     run = run && remaining > 0 && hs > 0;
   }
+  hp[0] = r0; hp[64] = r1; hp[128] = r2;
   // every BFU that ever entered the heap now sits in slots [0, hs0) with its final word length
   res0 = res1 = res2 = res3 = 0;
   for (int k = 0; k < hs0; k++) {
