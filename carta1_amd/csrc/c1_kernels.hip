@@ -20,6 +20,7 @@
 #include "c1_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -202,24 +203,6 @@ __device__ __forceinline__ int scale_factor_index(float maxabs, TablesPtr T) {
 // =====================================================================================================
 // k_analysis
 // =====================================================================================================
-struct alignas(16) AnalysisLds {
-  // state carried from frame to frame == the encoder half of BufferPool (buffers.js:30-59)
-  double d1[46];        // stage-1 QMF delay line (as doubles of binary32 values)
-  double d2[46];        // stage-2 QMF delay line
-  alignas(16) float band[512];      // low128 | mid128 | high256 of the current frame (never windowed in place)
-  float hi[39 + 256];   // delayed high band (encoder.js:84-90)
-  float ovl[96];        // mdctOverlap, 3 x 32
-  float mag[2][256];    // transientDetection magnitudes, current / previous (ping-pong)
-  double sums[18];
-  alignas(4) uint8_t sfi[64];
-  // scratch with disjoint lifetimes inside one frame
-  union alignas(16) {
-    struct { alignas(16) double w1[592]; alignas(16) double w2[320]; } q;                               // QMF work buffers
-    struct { alignas(16) float in[1024]; float re[256]; float im[256]; alignas(16) float coef[512]; } m;  // MDCT
-    struct { float re[512]; float im[512]; double term[4][256]; } t;              // transient detection
-  } u;
-};
-
 // mode-dependent geometry of the 256 complex FFT points of one frame: band 0 -> [0,64), band 1 ->
 // [64,128), band 2 -> [128,256); a long band is one transform, a short band is 16-point blocks.
 struct FrameModes {
@@ -231,285 +214,17 @@ struct FrameModes {
   }
 };
 
-template <bool DETECT>
-__global__ __launch_bounds__(C1_WAVE, 2) void k_analysis(C1EncodeLaunch L) {
-  __shared__ AnalysisLds S;
-  const C1DevEncOpts *O = L.opts;
-  const int lane0 = threadIdx.x;
-  int lane = lane0;
-  const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFrames;
-  const float *__restrict__ pcm = L.pcm[ch];
-
-  // zero state == stream start (buffers.js:30-59)
-  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
-  for (int i = lane; i < 39; i += 64) S.hi[i] = 0.0f;
-  for (int i = lane; i < 96; i += 64) S.ovl[i] = 0.0f;
-  for (int i = lane; i < 512; i += 64) (&S.mag[0][0])[i] = 0.0f;
-  int cur = 0;                                           // which half of S.mag is "current"
-  double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;   // lane b < 3: features of the previous frame, band b
-  __syncthreads();
-
-  const int warm = DETECT ? 2 : 1;
-  const int64_t f_end = (f0 + kRunFrames < L.frames) ? f0 + kRunFrames : L.frames;
-  for (int64_t f = f0 - warm; f < f_end; ++f) {
-    if (f < -(int64_t)L.halo_frames) continue;   // before the stream start: all-zero frame leaves the zero state
-    const bool qmf_only = (f == f0 - 2);         // detect warm-up frame -2 only feeds the delay lines
-    const bool emit = (f >= f0);
-    TablesPtr T = tables_for_this_frame(L.tables);
-    lane = lane_for_this_frame(lane0);
-
-    // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
-    {
-      const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f * 512);
-      const float4 a = p4[lane], b = p4[64 + lane];
-      double *w1 = S.u.q.w1;
-      if (lane < 46) w1[pidx(lane)] = S.d1[lane];
-      const int e0 = 46 + 4 * lane;
-      w1[pidx(e0 + 0)] = (double)a.x; w1[pidx(e0 + 1)] = (double)a.y;
-      w1[pidx(e0 + 2)] = (double)a.z; w1[pidx(e0 + 3)] = (double)a.w;
-      w1[pidx(e0 + 256)] = (double)b.x; w1[pidx(e0 + 257)] = (double)b.y;
-      w1[pidx(e0 + 258)] = (double)b.z; w1[pidx(e0 + 259)] = (double)b.w;
-    }
-    __syncthreads();
-    {
-      double ev[4], od[4];
-      qmf_analysis_core<4>(S.u.q.w1, lane, T, ev, od);
-      double *w2 = S.u.q.w2;
-      if (lane < 46) { w2[pidx(lane)] = S.d2[lane]; S.d1[lane] = S.u.q.w1[pidx(512 + lane)]; }
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const float lo = f32(ev[d] + od[d]);   // qmf.js:44-45
-        const float hi = f32(ev[d] - od[d]);
-        w2[pidx(46 + 4 * lane + d)] = (double)lo;
-        S.hi[39 + 4 * lane + d] = hi;
-      }
-    }
-    __syncthreads();
-    {
-      double ev[2], od[2];
-      qmf_analysis_core<2>(S.u.q.w2, lane, T, ev, od);
-#pragma unroll
-      for (int d = 0; d < 2; d++) {
-        S.band[2 * lane + d] = f32(ev[d] + od[d]);
-        S.band[128 + 2 * lane + d] = f32(ev[d] - od[d]);
-      }
-#pragma unroll
-      for (int m = 0; m < 4; m++) S.band[256 + lane + 64 * m] = S.hi[lane + 64 * m];
-      if (lane < 46) S.d2[lane] = S.u.q.w2[pidx(256 + lane)];
-    }
-    __syncthreads();
-    {
-      float keep = 0.0f;
-      if (lane < 39) keep = S.hi[256 + lane];
-      __syncthreads();
-      if (lane < 39) S.hi[lane] = keep;
-    }
-    if (qmf_only) { __syncthreads(); continue; }
-
-    if (emit && L.bands) {
-      float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
-      const float4 *src = reinterpret_cast<const float4 *>(S.band);
-      dst[lane] = src[lane];
-      dst[64 + lane] = src[64 + lane];
-    }
-
-    // ---------------- blockSelectorStage (encoder.js:111-152) ----------------
-    FrameModes M{O->modes[0], O->modes[1], O->modes[2]};
-    if (DETECT) {
-      float *re = S.u.t.re, *im = S.u.t.im;
-      float *mcur = S.mag[cur];
-      const float *mprev = S.mag[cur ^ 1];
-      // performFFT (transient.js:17-35): real input, three transforms 128 | 128 | 256 in one buffer
-#pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int p = lane + 64 * m;
-        const int base = p < 128 ? 0 : (p < 256 ? 128 : 256);
-        const int lg = p < 256 ? 7 : 8;
-        re[base + bitrev(p - base, lg)] = S.band[p];
-        im[p] = 0.0f;
-      }
-      __syncthreads();
-      fft_stages<512>(re, im, lane, T, 256, [](int e) { return e < 256 ? 128 : 256; });
-      // magnitudes of the positive-frequency half (transient.js:29-32) + per-bin terms of the features
-      bool valid[4];
-#pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const int g = lane + 64 * m;                        // mag index: band0 [0,64) band1 [64,128) band2 [128,256)
-        const int src = g < 64 ? g : (g < 128 ? 128 + (g - 64) : 256 + (g - 128));
-        const double r = re[src], i = im[src];
-        const float mg = f32(sqrt(r * r + i * i));
-        mcur[g] = mg;
-        const double cm = (double)mg, pm = (double)mprev[g];
-        const double diff = cm - pm;
-        valid[m] = cm > 1e-10;
-        S.u.t.term[0][g] = diff > 0 ? diff : 0.0;           // spectral flux terms (transient.js:96-106)
-        S.u.t.term[1][g] = cm * cm;                         // energy terms (exact product)
-        S.u.t.term[2][g] = valid[m] ? log(cm) : 0.0;        // flatness terms (transient.js:126-133)
-        S.u.t.term[3][g] = valid[m] ? cm : 0.0;
-      }
-      const int nv0 = __popcll(__ballot(valid[0])), nv1 = __popcll(__ballot(valid[1]));
-      const int nv2 = __popcll(__ballot(valid[2])) + __popcll(__ballot(valid[3]));
-      __syncthreads();
-      // the reference accumulates every feature sequentially in double, index ascending; keep that
-      // order: 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high})
-      if (lane < 18) {
-        const int b = lane / 6, kind = lane - 6 * b;
-        const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
-        const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
-        const int start = g0 + (kind == 5 ? n / 2 : 0);
-        const int len = kind >= 4 ? n / 2 : n;
-        const double *arr = S.u.t.term[which] + start;
-        double acc = 0.0;
-        for (int i = 0; i < len; i++) acc += arr[i];
-        S.sums[lane] = acc;
-      }
-      __syncthreads();
-      int mode = 0;
-      if (lane < 3) {
-        const double s_flux = S.sums[6 * lane + 0], s_e = S.sums[6 * lane + 1], s_log = S.sums[6 * lane + 2];
-        const double s_lin = S.sums[6 * lane + 3], s_lo = S.sums[6 * lane + 4], s_hi = S.sums[6 * lane + 5];
-        const int nv = lane == 0 ? nv0 : (lane == 1 ? nv1 : nv2);
-        double norm = sqrt(s_e);
-        if (!(norm != 0.0)) norm = 1e-6;                     // `Math.sqrt(e) || 1e-6`
-        const double flux = s_flux / norm;
-        double flat = 0.0;                                    // calculateSpectralFlatness :120-141
-        if (nv > 0) {
-          const double gm = exp(s_log / (double)nv), am = s_lin / (double)nv;
-          flat = am > 1e-10 ? gm / am : 0.0;
-        }
-        const double tot = s_lo + s_hi;                       // calculateHighFrequencyRatio :149-164
-        const double hf = tot > 0 ? s_hi / tot : 0.0;
-        const double ce = s_e > 1e-10 ? s_e : 1e-10;          // calculateEnergyChange :172-189
-        const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
-        const double db = 10.0 * log10(ce / pe);
-        const double e_change = db > 0 ? db : 0.0;
-        const double flat_c = sqrt(fabs(flat - prev_flat));   // calculateTransientScore :197-226
-        const double hf_c = log1p(fabs(hf - prev_hf) * 10.0) / T->log1p10;
-        const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
-        const double score = (flux + flat_c + hf_c + e_c) / 4.0;
-        mode = (score > O->threshold) ? (lane + 1 > 2 ? lane + 1 : 2) : 0;   // encoder.js:143
-        prev_flat = flat; prev_hf = hf; prev_e = s_e;
-      }
-      M.m0 = __shfl(mode, 0); M.m1 = __shfl(mode, 1); M.m2 = __shfl(mode, 2);
-      cur ^= 1;
-      __syncthreads();
-    }
-
-    // ---------------- mdctStage (encoder.js:170-349) ----------------
-    float *in = S.u.m.in, *re = S.u.m.re, *im = S.u.m.im, *coef = S.u.m.coef;
-    if (emit) {
-      // MDCT inputs of the three bands (long: zero | overlap | samples with windowed tail | zero,
-      // encoder.js:228-258; short: [overlap | windowed block] per 32-sample block, :269-307)
-#pragma unroll
-      for (int m = 0; m < 16; m++) {
-        const int g = lane + 64 * m;
-        const int b = g < 256 ? 0 : (g < 512 ? 1 : 2);
-        const int l = g - (b == 0 ? 0 : (b == 1 ? 256 : 512));
-        const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-        float v = 0.0f;
-        if (M.mode_of_band(b) == 0) {
-          const int ws = b == 2 ? 112 : 48;
-          const int x = l - ws - 32;
-          if (l >= ws && l < ws + 32) v = S.ovl[32 * b + (l - ws)];
-          else if (x >= 0 && x < Sb - 32) v = S.band[off + x];
-          else if (x >= Sb - 32 && x < Sb) v = f32((double)S.band[off + x] * T->window[31 - (x - (Sb - 32))]);
-        } else {
-          const int q = l >> 6, pos = l & 63;
-          if (pos < 32) v = q == 0 ? S.ovl[32 * b + pos] : f32(T->window[pos] * (double)S.band[off + 32 * (q - 1) + pos]);
-          else v = f32((double)S.band[off + 32 * q + (pos - 32)] * T->window[31 - (pos - 32)]);
-        }
-        in[g] = v;
-      }
-      __syncthreads();
-    }
-    // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
-    for (int i = lane; i < 96; i += 64) {
-      const int b = i >> 5, k = i & 31;
-      const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-      S.ovl[i] = f32(T->window[k] * (double)S.band[off + Sb - 32 + k]);
-    }
-    if (!emit) { __syncthreads(); continue; }
-
-    // pre-twiddle (mdct.js:76-105) straight into bit-reversed order
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int p = lane + 64 * m;
-      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
-      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), ibase = b == 0 ? 0 : (b == 1 ? 256 : 512);
-      const bool lng = M.mode_of_band(b) == 0;
-      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
-      const int lg = lng ? (b == 2 ? 7 : 6) : 4;
-      const int q = lng ? 0 : ((p - cbase) >> 4);
-      const int k = (p - cbase) - q * nfft;
-      const float *x = in + ibase + q * 64;
-      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
-      const int n4 = nfft, n34 = 3 * nfft, i = 2 * k;
-      double r, mm;
-      if (i < n4) { r = (double)x[n34 - 1 - i] + (double)x[n34 + i]; mm = (double)x[n4 + i] - (double)x[n4 - 1 - i]; }
-      else { r = (double)x[n34 - 1 - i] - (double)x[i - n4]; mm = (double)x[n4 + i] + (double)x[5 * n4 - 1 - i]; }
-      const double c = tab[i], s = tab[i + 1];
-      const int dst = cbase + q * nfft + bitrev(k, lg);
-      re[dst] = f32(r * c + mm * s);
-      im[dst] = f32(mm * c - r * s);
-    }
-    __syncthreads();
-    fft_stages<256>(re, im, lane, T, 128, [&](int e) { return M.fft_size_at(e); });
-    // post-twiddle (mdct.js:110-119) + spectrum reversal of bands 1,2 (utils.js:42-48)
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int p = lane + 64 * m;
-      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
-      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
-      const bool lng = M.mode_of_band(b) == 0;
-      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
-      const int q = lng ? 0 : ((p - cbase) >> 4);
-      const int i = (p - cbase) - q * nfft;
-      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
-      const int n2 = 2 * nfft;
-      const double c = tab[2 * i], s = tab[2 * i + 1], rr = re[p], ii = im[p];
-      const float o0 = f32(-rr * c - ii * s);
-      const float o1 = f32(-rr * s + ii * c);
-      const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
-      float *dst = coef + obase + q * 32;
-      if (b > 0) { dst[n2 - 1 - j0] = o0; dst[n2 - 1 - j1] = o1; }
-      else { dst[j0] = o0; dst[j1] = o1; }
-    }
-    __syncthreads();
-
-    // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
-    const int64_t unit = f * L.channels + ch;
-    {
-      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
-      const float4 *src = reinterpret_cast<const float4 *>(coef);
-      dst[lane] = src[lane];
-      dst[64 + lane] = src[64 + lane];
-    }
-    if (lane < 52) {
-      const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
-      const int n = kSpecs[lane];
-      float mx = 0.0f;
-      for (int j = 0; j < n; j++) {
-        const float a = fabsf(coef[start + j]);
-        if (a > mx) mx = a;
-      }
-      S.sfi[lane] = (uint8_t)scale_factor_index(mx, T);
-    } else {
-      S.sfi[lane] = lane == 52 ? (uint8_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0;
-    }
-    __syncthreads();
-    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-    __syncthreads();
-  }
-}
-
 // =====================================================================================================
-// k_analysis_long : the same stage chain specialised for fixed block modes [0,0,0] (all bands long)
+// k_analysis_fast : QMF -> block selection -> MDCT -> scale factors, one wave per run of frames
 // =====================================================================================================
-// Every vector instruction costs the same 4 cycles here, so this path is shaped to minimise their count:
-// the MDCT inputs of the three bands live in LDS buffers whose zero regions are written once per wave,
-// the FFT works on interleaved (re,im) pairs with compile-time strides, and there is no per-element
-// mode logic.  Numerics are identical to k_analysis (same operations in the same order).
+// template <DETECT, ALL_LONG>:
+//   <false,true>   fixed block modes [0,0,0]: the long-block MDCT core below and nothing else
+//   <false,false>  any other fixed modes: frames go through the generic (mode-aware) MDCT staging
+//   <true,false>   transient detection: per frame the three block modes are decided, then all-long frames
+//                  (the common case) take the long-block core and the rest the generic staging
+// Every vector instruction costs the same 4 cycles here, so the long-block core is shaped to minimise
+// their count: MDCT inputs in LDS buffers, FFT on interleaved (re,im) pairs with lane-only geometry
+// computed once per wave, bank-conflict-free layouts (tools/lds_model.py), no per-element mode logic.
 struct alignas(16) LongLds {
   double d1[46];                 // stage-1 QMF delay line
   double d2[46];                 // stage-2 QMF delay line
@@ -525,8 +240,36 @@ struct alignas(16) LongLds {
         struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // MDCT inputs
         struct { alignas(16) float coef[512]; } c;                                                           // coefficients (after the pre-twiddle)
       } a;
-      alignas(16) float2 z[256];                                                                             // FFT points
+      union alignas(16) { float2 z[256]; } zz;                                                               // FFT points
     } m;
+  } u;
+};
+
+struct alignas(16) MixedLds {
+  double d1[46];
+  double d2[46];
+  alignas(16) float band[512];
+  alignas(16) float hbuf[296];
+  alignas(4) uint8_t sfi[64];
+  float ovl[96];                 // mdctOverlap, 3 x 32 (the all-long kernel keeps it in registers)
+  float mag[2][256];             // transientDetection magnitudes, current / previous (ping-pong)
+  double sums[18];
+  union alignas(16) {
+    struct { alignas(16) double w1[698]; } q1;
+    struct { alignas(16) double w2[454]; } q2;
+    struct {
+      union alignas(16) {
+        struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // long-block inputs
+        struct { alignas(16) float in[1024]; } g;                                                            // generic staging
+        struct { alignas(16) float coef[512]; } c;
+      } a;
+      union alignas(16) {
+        float2 z[256];
+        struct { float re[256]; float im[256]; } ri;
+      } zz;
+    } m;
+    struct { float re[512]; float im[512]; } t;      // transient FFT: 128 | 128 | 256 points
+    struct { double term[4][256]; } tt;              // per-bin feature terms (after the magnitudes are taken)
   } u;
 };
 
@@ -603,8 +346,12 @@ __device__ __forceinline__ void mdct_post(const float2 *z, int slot, const __att
   else { dst[2 * i] = o0; dst[n2 - 1 - 2 * i] = o1; }
 }
 
-__global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) {
-  __shared__ LongLds S;
+template <bool DETECT, bool ALL_LONG>
+__global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_analysis_fast(C1EncodeLaunch L) {
+  static_assert(!(DETECT && ALL_LONG), "detection decides the modes per frame");
+  using Lds = typename std::conditional<ALL_LONG, LongLds, MixedLds>::type;
+  __shared__ Lds S;
+  const C1DevEncOpts *O = L.opts;
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
@@ -614,6 +361,12 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
   if (lane < 12) S.sfi[52 + lane] = 0;   // modes byte (all long) and padding of the side record
+  if constexpr (!ALL_LONG) {
+    for (int i = lane; i < 96; i += 64) S.ovl[i] = 0.0f;
+    for (int i = lane; i < 512; i += 64) (&S.mag[0][0])[i] = 0.0f;
+  }
+  int cur = 0;                                           // which half of S.mag is "current"
+  double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;   // lane b < 3: features of the previous frame, band b
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   // lane-only geometry of the MDCT core, computed once (everything else is re-derived per frame)
   const PreGeometry g256a = pre_geometry<64, 6>(lane0, 0), g256b = pre_geometry<64, 6>(lane0, 64);
@@ -626,7 +379,10 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
-  const int64_t f_first = (f0 - 1 < -(int64_t)L.halo_frames) ? f0 : f0 - 1;   // before the stream start the zero state stays
+  constexpr int kWarm = DETECT ? 2 : 1;            // frames of history that rebuild the state
+  int64_t f_first = f0 - kWarm;
+  if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;   // before the stream start the zero state stays
+  if (f_first > f0) f_first = f0;
   // the PCM of the next frame is fetched while the current one is processed (two 16-byte loads per lane)
   float4 pre_a, pre_b;
   {
@@ -635,6 +391,7 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
   }
   for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = (f >= f0);
+    const bool qmf_only = DETECT && (f == f0 - 2);   // detect warm-up frame -2 only feeds the delay lines
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
 
@@ -684,6 +441,7 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
       __syncthreads();
       if (lane < 39) S.hbuf[lane] = keep;
     }
+    if (qmf_only) { __syncthreads(); continue; }
     if (emit && L.bands) {
       float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
       const float4 *src = reinterpret_cast<const float4 *>(S.band);
@@ -691,92 +449,387 @@ __global__ __launch_bounds__(C1_WAVE, 4) void k_analysis_long(C1EncodeLaunch L) 
       dst[64 + lane] = src[64 + lane];
     }
 
-    // ---------------- mdctStage, long blocks (encoder.js:228-258, 309-316) ----------------
-    // tail of every band: windowed copy into this frame's MDCT input, overlap for the next frame
-    float *in0 = S.u.m.a.i.in0, *in1 = S.u.m.a.i.in1, *in2 = S.u.m.a.i.in2;
-    float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
-    if (lane < 32) {
-      const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
-      const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
-      nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
-      if (emit) {
-        in0[48 + lane] = ov0; in1[48 + lane] = ov1; in2[112 + lane] = ov2;     // overlap saved by the previous frame
-        in0[80 + 96 + lane] = f32(x0 * w_hi);
-        in1[80 + 96 + lane] = f32(x1 * w_hi);
-        in2[144 + 224 + lane] = f32(x2 * w_hi);
+    if constexpr (ALL_LONG) {
+      // ---------------- mdctStage, long blocks (encoder.js:228-258, 309-316) ----------------
+      // tail of every band: windowed copy into this frame's MDCT input, overlap for the next frame
+      float *in0 = S.u.m.a.i.in0, *in1 = S.u.m.a.i.in1, *in2 = S.u.m.a.i.in2;
+      float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
+      if (lane < 32) {
+        const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
+        const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
+        nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
+        if (emit) {
+          in0[48 + lane] = ov0; in1[48 + lane] = ov1; in2[112 + lane] = ov2;     // overlap saved by the previous frame
+          in0[80 + 96 + lane] = f32(x0 * w_hi);
+          in1[80 + 96 + lane] = f32(x1 * w_hi);
+          in2[144 + 224 + lane] = f32(x2 * w_hi);
+        }
       }
-    }
-    ov0 = nov0; ov1 = nov1; ov2 = nov2;
-    if (!emit) { __syncthreads(); continue; }
-    // zero regions and the body of every band (everything before the tail) straight into the MDCT inputs
-    {
-      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (lane < 48) {
-        float *inb = lane < 24 ? in0 : in1;
-        const int q = lane < 24 ? lane : lane - 24;                 // 24 float4 per band: [0,48) and [208,256)
-        *reinterpret_cast<float4 *>(&inb[q < 12 ? 4 * q : 208 + 4 * (q - 12)]) = zero4;
+      ov0 = nov0; ov1 = nov1; ov2 = nov2;
+      if (!emit) { __syncthreads(); continue; }
+      // zero regions and the body of every band (everything before the tail) straight into the MDCT inputs
+      {
+        const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lane < 48) {
+          float *inb = lane < 24 ? in0 : in1;
+          const int q = lane < 24 ? lane : lane - 24;                 // 24 float4 per band: [0,48) and [208,256)
+          *reinterpret_cast<float4 *>(&inb[q < 12 ? 4 * q : 208 + 4 * (q - 12)]) = zero4;
+        }
+        if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
+        if (lane < 48) {
+          *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
+          *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+        }
+        if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
       }
-      if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
-      if (lane < 48) {
-        *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
-        *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+      __syncthreads();
+      float2 *z = S.u.m.zz.z;
+      if (!(L.debug & 32)) {
+      mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256a, z);
+      mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256b, z);
+      mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
+      mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
       }
-      if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
-    }
-    __syncthreads();
-    float2 *z = S.u.m.z;
-    if (!(L.debug & 32)) {
-    mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256a, z);
-    mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256b, z);
-    mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
-    mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
-    }
-    __syncthreads();
-    // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
-    if (!(L.debug & 8)) {
-    fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
-    fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
-    fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
-    fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
-    fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
-    fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
-    fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
-    }
-    float *coef = S.u.m.a.c.coef;
-    if (!(L.debug & 32)) {
-    mdct_post<64, false>(z, ps0, T->mdct_fwd256, lane, coef);
-    mdct_post<64, true>(z, ps1, T->mdct_fwd256, lane, coef + 128);
-    mdct_post<128, true>(z + 128, ps0, T->mdct_fwd512, lane, coef + 256);
-    mdct_post<128, true>(z + 128, ps1, T->mdct_fwd512, lane + 64, coef + 256);
-    }
-    __syncthreads();
+      __syncthreads();
+      // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
+      if (!(L.debug & 8)) {
+      fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
+      fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
+      fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
+      fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
+      fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
+      fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
+      fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
+      }
+      float *coef = S.u.m.a.c.coef;
+      if (!(L.debug & 32)) {
+      mdct_post<64, false>(z, ps0, T->mdct_fwd256, lane, coef);
+      mdct_post<64, true>(z, ps1, T->mdct_fwd256, lane, coef + 128);
+      mdct_post<128, true>(z + 128, ps0, T->mdct_fwd512, lane, coef + 256);
+      mdct_post<128, true>(z + 128, ps1, T->mdct_fwd512, lane + 64, coef + 256);
+      }
+      __syncthreads();
 
-    // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
-    const int64_t unit = f * L.channels + ch;
-    {
-      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
-      const float4 *src = reinterpret_cast<const float4 *>(coef);
-      dst[lane] = src[lane];
-      dst[64 + lane] = src[64 + lane];
-    }
-    {
-      // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
-      // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
-      const bool wide = lane >= 44;
-      const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
-      const int half = wide ? (lane & 1) : 0;
-      const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
-      const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
-      float mx = 0.0f;
+      // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+      const int64_t unit = f * L.channels + ch;
+      {
+        float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+        const float4 *src = reinterpret_cast<const float4 *>(coef);
+        dst[lane] = src[lane];
+        dst[64 + lane] = src[64 + lane];
+      }
+      {
+        // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
+        // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
+        const bool wide = lane >= 44;
+        const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
+        const int half = wide ? (lane & 1) : 0;
+        const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
+        const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
+        float mx = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
-      mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
-      const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
-      if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
+        for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
+        mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
+        const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+        if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
+        if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
+      }
+      __syncthreads();
+      if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+      __syncthreads();
+    } else {
+      // ---------------- blockSelectorStage (encoder.js:111-152) ----------------
+      FrameModes M{O->modes[0], O->modes[1], O->modes[2]};
+      if (DETECT) {
+        float *re = S.u.t.re, *im = S.u.t.im;
+        float *mcur = S.mag[cur];
+        const float *mprev = S.mag[cur ^ 1];
+        // performFFT (transient.js:17-35): real input, three transforms 128 | 128 | 256 in one buffer
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int p = lane + 64 * m;
+          const int base = p < 128 ? 0 : (p < 256 ? 128 : 256);
+          const int lg = p < 256 ? 7 : 8;
+          re[base + bitrev(p - base, lg)] = S.band[p];
+          im[p] = 0.0f;
+        }
+        __syncthreads();
+        fft_stages<512>(re, im, lane, T, 256, [](int e) { return e < 256 ? 128 : 256; });
+        // magnitudes of the positive-frequency half (transient.js:29-32) + per-bin terms of the features
+        bool valid[4];
+        float mgs[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int g = lane + 64 * m;                        // mag index: band0 [0,64) band1 [64,128) band2 [128,256)
+          const int src = g < 64 ? g : (g < 128 ? 128 + (g - 64) : 256 + (g - 128));
+          const double r = re[src], i = im[src];
+          mgs[m] = f32(sqrt(r * r + i * i));
+        }
+        __syncthreads();                                      // the per-bin terms reuse the memory of re/im
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int g = lane + 64 * m;
+          const float mg = mgs[m];
+          mcur[g] = mg;
+          const double cm = (double)mg, pm = (double)mprev[g];
+          const double diff = cm - pm;
+          valid[m] = cm > 1e-10;
+          S.u.tt.term[0][g] = diff > 0 ? diff : 0.0;          // spectral flux terms (transient.js:96-106)
+          S.u.tt.term[1][g] = cm * cm;                        // energy terms (exact product)
+          S.u.tt.term[2][g] = valid[m] ? log(cm) : 0.0;       // flatness terms (transient.js:126-133)
+          S.u.tt.term[3][g] = valid[m] ? cm : 0.0;
+        }
+        const int nv0 = __popcll(__ballot(valid[0])), nv1 = __popcll(__ballot(valid[1]));
+        const int nv2 = __popcll(__ballot(valid[2])) + __popcll(__ballot(valid[3]));
+        __syncthreads();
+        // the reference accumulates every feature sequentially in double, index ascending; keep that
+        // order: 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high})
+        if (lane < 18) {
+          const int b = lane / 6, kind = lane - 6 * b;
+          const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
+          const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
+          const int start = g0 + (kind == 5 ? n / 2 : 0);
+          const int len = kind >= 4 ? n / 2 : n;
+          const double *arr = S.u.tt.term[which] + start;
+          double acc = 0.0;
+          for (int i = 0; i < len; i++) acc += arr[i];
+          S.sums[lane] = acc;
+        }
+        __syncthreads();
+        int mode = 0;
+        if (lane < 3) {
+          const double s_flux = S.sums[6 * lane + 0], s_e = S.sums[6 * lane + 1], s_log = S.sums[6 * lane + 2];
+          const double s_lin = S.sums[6 * lane + 3], s_lo = S.sums[6 * lane + 4], s_hi = S.sums[6 * lane + 5];
+          const int nv = lane == 0 ? nv0 : (lane == 1 ? nv1 : nv2);
+          double norm = sqrt(s_e);
+          if (!(norm != 0.0)) norm = 1e-6;                     // `Math.sqrt(e) || 1e-6`
+          const double flux = s_flux / norm;
+          double flat = 0.0;                                    // calculateSpectralFlatness :120-141
+          if (nv > 0) {
+            const double gm = exp(s_log / (double)nv), am = s_lin / (double)nv;
+            flat = am > 1e-10 ? gm / am : 0.0;
+          }
+          const double tot = s_lo + s_hi;                       // calculateHighFrequencyRatio :149-164
+          const double hf = tot > 0 ? s_hi / tot : 0.0;
+          const double ce = s_e > 1e-10 ? s_e : 1e-10;          // calculateEnergyChange :172-189
+          const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
+          const double db = 10.0 * log10(ce / pe);
+          const double e_change = db > 0 ? db : 0.0;
+          const double flat_c = sqrt(fabs(flat - prev_flat));   // calculateTransientScore :197-226
+          const double hf_c = log1p(fabs(hf - prev_hf) * 10.0) / T->log1p10;
+          const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
+          const double score = (flux + flat_c + hf_c + e_c) / 4.0;
+          mode = (score > O->threshold) ? (lane + 1 > 2 ? lane + 1 : 2) : 0;   // encoder.js:143
+          prev_flat = flat; prev_hf = hf; prev_e = s_e;
+        }
+        M.m0 = __shfl(mode, 0); M.m1 = __shfl(mode, 1); M.m2 = __shfl(mode, 2);
+        cur ^= 1;
+        __syncthreads();
+      }
+
+      if (!emit) {
+        // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
+        for (int i = lane; i < 96; i += 64) {
+          const int b = i >> 5, k = i & 31;
+          const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+          S.ovl[i] = f32(T->window[k] * (double)S.band[off + Sb - 32 + k]);
+        }
+        __syncthreads();
+        continue;
+      }
+      if (M.m0 == 0 && M.m1 == 0 && M.m2 == 0) {
+        // ---------------- mdctStage, long blocks (encoder.js:228-258, 309-316) ----------------
+        // tail of every band: windowed copy into this frame's MDCT input, overlap for the next frame
+        float *in0 = S.u.m.a.i.in0, *in1 = S.u.m.a.i.in1, *in2 = S.u.m.a.i.in2;
+        float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
+        if (lane < 32) {
+          const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
+          const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
+          nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
+          if (emit) {
+            in0[48 + lane] = S.ovl[lane]; in1[48 + lane] = S.ovl[32 + lane]; in2[112 + lane] = S.ovl[64 + lane];
+            in0[80 + 96 + lane] = f32(x0 * w_hi);
+            in1[80 + 96 + lane] = f32(x1 * w_hi);
+            in2[144 + 224 + lane] = f32(x2 * w_hi);
+          }
+        }
+        if (lane < 32) { S.ovl[lane] = nov0; S.ovl[32 + lane] = nov1; S.ovl[64 + lane] = nov2; }
+        // zero regions and the body of every band (everything before the tail) straight into the MDCT inputs
+        {
+          const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (lane < 48) {
+            float *inb = lane < 24 ? in0 : in1;
+            const int q = lane < 24 ? lane : lane - 24;                 // 24 float4 per band: [0,48) and [208,256)
+            *reinterpret_cast<float4 *>(&inb[q < 12 ? 4 * q : 208 + 4 * (q - 12)]) = zero4;
+          }
+          if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
+          if (lane < 48) {
+            *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
+            *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+          }
+          if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
+        }
+        __syncthreads();
+        float2 *z = S.u.m.zz.z;
+        if (!(L.debug & 32)) {
+        mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256a, z);
+        mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256b, z);
+        mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
+        mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
+        }
+        __syncthreads();
+        // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
+        if (!(L.debug & 8)) {
+        fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
+        fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
+        fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
+        fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
+        fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
+        fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
+        fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
+        }
+        float *coef = S.u.m.a.c.coef;
+        if (!(L.debug & 32)) {
+        mdct_post<64, false>(z, ps0, T->mdct_fwd256, lane, coef);
+        mdct_post<64, true>(z, ps1, T->mdct_fwd256, lane, coef + 128);
+        mdct_post<128, true>(z + 128, ps0, T->mdct_fwd512, lane, coef + 256);
+        mdct_post<128, true>(z + 128, ps1, T->mdct_fwd512, lane + 64, coef + 256);
+        }
+        __syncthreads();
+
+        // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+        const int64_t unit = f * L.channels + ch;
+        {
+          float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+          const float4 *src = reinterpret_cast<const float4 *>(coef);
+          dst[lane] = src[lane];
+          dst[64 + lane] = src[64 + lane];
+        }
+        {
+          // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
+          // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
+          const bool wide = lane >= 44;
+          const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
+          const int half = wide ? (lane & 1) : 0;
+          const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
+          const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
+          float mx = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
+          mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
+          const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+          if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
+          if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
+        }
+        __syncthreads();
+        if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+        __syncthreads();
+      } else {
+        // ---------------- mdctStage, any block modes (encoder.js:170-349) ----------------
+        float *in = S.u.m.a.g.in, *re = S.u.m.zz.ri.re, *im = S.u.m.zz.ri.im, *coef = S.u.m.a.c.coef;
+        if (emit) {
+          // MDCT inputs of the three bands (long: zero | overlap | samples with windowed tail | zero,
+          // encoder.js:228-258; short: [overlap | windowed block] per 32-sample block, :269-307)
+#pragma unroll
+          for (int m = 0; m < 16; m++) {
+            const int g = lane + 64 * m;
+            const int b = g < 256 ? 0 : (g < 512 ? 1 : 2);
+            const int l = g - (b == 0 ? 0 : (b == 1 ? 256 : 512));
+            const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+            float v = 0.0f;
+            if (M.mode_of_band(b) == 0) {
+              const int ws = b == 2 ? 112 : 48;
+              const int x = l - ws - 32;
+              if (l >= ws && l < ws + 32) v = S.ovl[32 * b + (l - ws)];
+              else if (x >= 0 && x < Sb - 32) v = S.band[off + x];
+              else if (x >= Sb - 32 && x < Sb) v = f32((double)S.band[off + x] * T->window[31 - (x - (Sb - 32))]);
+            } else {
+              const int q = l >> 6, pos = l & 63;
+              if (pos < 32) v = q == 0 ? S.ovl[32 * b + pos] : f32(T->window[pos] * (double)S.band[off + 32 * (q - 1) + pos]);
+              else v = f32((double)S.band[off + 32 * q + (pos - 32)] * T->window[31 - (pos - 32)]);
+            }
+            in[g] = v;
+          }
+          __syncthreads();
+        }
+        // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
+        for (int i = lane; i < 96; i += 64) {
+          const int b = i >> 5, k = i & 31;
+          const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+          S.ovl[i] = f32(T->window[k] * (double)S.band[off + Sb - 32 + k]);
+        }
+
+        // pre-twiddle (mdct.js:76-105) straight into bit-reversed order
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int p = lane + 64 * m;
+          const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+          const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), ibase = b == 0 ? 0 : (b == 1 ? 256 : 512);
+          const bool lng = M.mode_of_band(b) == 0;
+          const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
+          const int lg = lng ? (b == 2 ? 7 : 6) : 4;
+          const int q = lng ? 0 : ((p - cbase) >> 4);
+          const int k = (p - cbase) - q * nfft;
+          const float *x = in + ibase + q * 64;
+          const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
+          const int n4 = nfft, n34 = 3 * nfft, i = 2 * k;
+          double r, mm;
+          if (i < n4) { r = (double)x[n34 - 1 - i] + (double)x[n34 + i]; mm = (double)x[n4 + i] - (double)x[n4 - 1 - i]; }
+          else { r = (double)x[n34 - 1 - i] - (double)x[i - n4]; mm = (double)x[n4 + i] + (double)x[5 * n4 - 1 - i]; }
+          const double c = tab[i], s = tab[i + 1];
+          const int dst = cbase + q * nfft + bitrev(k, lg);
+          re[dst] = f32(r * c + mm * s);
+          im[dst] = f32(mm * c - r * s);
+        }
+        __syncthreads();
+        fft_stages<256>(re, im, lane, T, 128, [&](int e) { return M.fft_size_at(e); });
+        // post-twiddle (mdct.js:110-119) + spectrum reversal of bands 1,2 (utils.js:42-48)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int p = lane + 64 * m;
+          const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
+          const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
+          const bool lng = M.mode_of_band(b) == 0;
+          const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
+          const int q = lng ? 0 : ((p - cbase) >> 4);
+          const int i = (p - cbase) - q * nfft;
+          const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
+          const int n2 = 2 * nfft;
+          const double c = tab[2 * i], s = tab[2 * i + 1], rr = re[p], ii = im[p];
+          const float o0 = f32(-rr * c - ii * s);
+          const float o1 = f32(-rr * s + ii * c);
+          const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
+          float *dst = coef + obase + q * 32;
+          if (b > 0) { dst[n2 - 1 - j0] = o0; dst[n2 - 1 - j1] = o1; }
+          else { dst[j0] = o0; dst[j1] = o1; }
+        }
+        __syncthreads();
+
+        // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+        const int64_t unit = f * L.channels + ch;
+        {
+          float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+          const float4 *src = reinterpret_cast<const float4 *>(coef);
+          dst[lane] = src[lane];
+          dst[64 + lane] = src[64 + lane];
+        }
+        if (lane < 52) {
+          const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
+          const int n = kSpecs[lane];
+          float mx = 0.0f;
+          for (int j = 0; j < n; j++) {
+            const float a = fabsf(coef[start + j]);
+            if (a > mx) mx = a;
+          }
+          S.sfi[lane] = (uint8_t)scale_factor_index(mx, T);
+        } else {
+          S.sfi[lane] = lane == 52 ? (uint8_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0;
+        }
+        __syncthreads();
+        if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-    __syncthreads();
   }
 }
 
@@ -1550,14 +1603,14 @@ __global__ void k_generate_pink(const uint32_t *segment_states, int64_t frames, 
 
 // ---- launchers -----------------------------------------------------------------------------------------
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFrames - 1) / kRunFrames;
+  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
   const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
-  if (detect) hipLaunchKernelGGL(k_analysis<true>, grid, block, 0, stream, L);
-  else hipLaunchKernelGGL(k_analysis<false>, grid, block, 0, stream, L);
+  if (detect) hipLaunchKernelGGL((k_analysis_fast<true, false>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_analysis_fast<false, false>), grid, block, 0, stream, L);
 }
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
-  hipLaunchKernelGGL(k_analysis_long, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+  hipLaunchKernelGGL((k_analysis_fast<false, true>), dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
 }
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
