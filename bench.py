@@ -169,7 +169,7 @@ def main():
     if rank == 0:
         total_frames = frames * world * args.steps
         value = total_frames / elapsed
-        kernel_names = {'analysis': 'k_analysis_long' if modes == [0, 0, 0] else ('k_analysis<true>' if modes is None else 'k_analysis<false>'),
+        kernel_names = {'analysis': 'k_analysis_fast<false, true>' if modes == [0, 0, 0] else ('k_analysis_fast<true, false>' if modes is None else 'k_analysis_fast<false, false>'),
                         'allocate': 'k_alloc_first+k_alloc_rest+k_alloc_select', 'pack': 'k_pack', 'decode': 'k_decode'}
         dom = max(kernel_ms, key=lambda k: kernel_ms[k]['ms_per_step'])
         dom_ms, dom_n = kernel_ms[dom]['ms_per_step'], max(1, kernel_ms[dom]['launches_per_step'])
