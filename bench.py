@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--signal', choices=['white', 'pink'], default='white')
     ap.add_argument('--decode', action='store_true', help='time decode of the encoded units instead')
     ap.add_argument('--cpu-sample', type=int, default=65536, help='stereo frames for the CPU baseline (0 = skip)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo for rehearsals')
+    ap.add_argument('--force-device', type=int, default=-1, help='rehearsal only: put every rank on this device')
     args = ap.parse_args()
 
     import torch
@@ -99,8 +101,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if args.force_device >= 0:
+            local_rank = args.force_device
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ctx = c1.Context(local_rank)
