@@ -1332,12 +1332,11 @@ struct alignas(16) DecodeLds {
   float dhi[39];        // high-band delay
   float tail[48];       // last 16 IMDCT samples per band (imdctOverlap tails, decoder.js:227-230)
   uint32_t words[56];   // the unit as big-endian words
-  int bit_off[53];
-  uint8_t wl[52], sfi[52];
-  float coef[512];
-  float band[512];
+  uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
+  alignas(16) float coef[512];
+  alignas(16) float band[512];
   union alignas(16) {
-    struct { float re[256]; float im[256]; float mid[512]; } m;   // IMDCT
+    struct { union alignas(16) { struct { float re[256]; float im[256]; } ri; float2 z[256]; } zz; alignas(16) float mid[512]; } m;   // IMDCT
     struct { alignas(16) double w2[454]; } q2;                   // stage-2 synthesis work buffer (padded 2 per 4)
     struct { alignas(16) double w1[698]; } q1;                   // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
   } u;
@@ -1353,6 +1352,38 @@ __device__ __forceinline__ uint32_t get_bits_be(const uint32_t *words, int pos, 
   return (uint32_t)((two >> (64 - o - nb)) & ((1ull << nb) - 1ull));
 }
 
+// ---- inverse MDCT, long blocks: lane-only geometry (computed once per wave) + the shared FFT core ----
+struct IPreGeometry { int ja, jb, zi; };
+template <int NFFT, int LG, bool REV>
+__device__ __forceinline__ IPreGeometry ipre_geometry(int i, int region_offset) {
+  constexpr int n2 = 2 * NFFT;
+  const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
+  IPreGeometry g;
+  g.ja = REV ? n2 - 1 - j0 : j0;       // bands 1,2 arrive spectrally reversed (decoder.js:183-186)
+  g.jb = REV ? n2 - 1 - j1 : j1;
+  g.zi = zsw(region_offset + bitrev(i, LG));
+  return g;
+}
+// pre-twiddle of point i (mdct.js:161-170)
+__device__ __forceinline__ void imdct_pre(const float *x, const __attribute__((address_space(4))) double *tab, int i,
+                                          const IPreGeometry &g, float2 *z) {
+  const double r = -(double)x[g.ja], mm = -(double)x[g.jb];
+  const double c = tab[2 * i], sn = tab[2 * i + 1];
+  z[g.zi] = make_float2(f32(mm * sn + r * c), f32(mm * c - r * sn));
+}
+// post-twiddle of point i (mdct.js:177-208), keeping only the middle half the decoder uses (decoder.js:191-199)
+template <int NFFT>
+__device__ __forceinline__ void imdct_post(const float2 *z, int slot, const __attribute__((address_space(4))) double *tab,
+                                           int i, float *dst) {
+  constexpr int n2 = 2 * NFFT;
+  const float2 zz = z[slot];
+  const double c = tab[2 * i], sn = tab[2 * i + 1], rr = zz.x, ii = zz.y;
+  const double r1 = rr * c + ii * sn, i1 = rr * sn - ii * c;
+  const int idx = (i < NFFT / 2) ? 2 * i : (2 * (i - NFFT / 2) + NFFT);
+  dst[n2 - 1 - idx] = f32(r1);
+  dst[idx] = f32(i1);
+}
+
 __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   __shared__ DecodeLds S;
   const int lane0 = threadIdx.x;
@@ -1365,6 +1396,24 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   for (int i = lane; i < 39; i += 64) S.dhi[i] = 0.0f;
   for (int i = lane; i < 48; i += 64) S.tail[i] = 0.0f;
   if (lane < 3) S.words[53 + lane] = 0u;
+  // lane-only geometry, computed once per wave
+  int slot_b[8], slot_j[8], at_long[8], at_short[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const int p = lane0 + 64 * m;                    // coefficient slot in BFU-major order
+    slot_b[m] = bfu_of_slot(p);
+    slot_j[m] = p - kBfuFirst[slot_b[m]];
+    at_long[m] = kStartLong[slot_b[m]] + slot_j[m];
+    at_short[m] = kStartShort[slot_b[m]] + slot_j[m];
+  }
+  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
+  const IPreGeometry ig256a = ipre_geometry<64, 6, false>(lane0, 0), ig256b = ipre_geometry<64, 6, true>(lane0, 64);
+  const IPreGeometry ig512a = ipre_geometry<128, 7, true>(lane0, 0), ig512b = ipre_geometry<128, 7, true>(lane0 + 64, 0);
+  int fe1, fe2, fe4, fe8, fe16, fe32, fe64, fo1, fo2, fo4, fo8, fo16, fo32, fo64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
+  butterfly_geometry<1>(lane0, fe1, fo1, ft1); butterfly_geometry<2>(lane0, fe2, fo2, ft2); butterfly_geometry<4>(lane0, fe4, fo4, ft4);
+  butterfly_geometry<8>(lane0, fe8, fo8, ft8); butterfly_geometry<16>(lane0, fe16, fo16, ft16); butterfly_geometry<32>(lane0, fe32, fo32, ft32);
+  butterfly_geometry<64>(lane0, fe64, fo64, ft64);
+  const int ps0 = zsw(lane0), ps1 = zsw(64 + lane0);
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesDecode < L.frames) ? f0 + kRunFramesDecode : L.frames;
@@ -1377,52 +1426,88 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
 
     // ---------------- deserializeFrame (serialization.js:111-176) ----------------
     if (lane < 53) S.words[lane] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane]);
-#pragma unroll
-    for (int m = 0; m < 8; m++) S.coef[lane + 64 * m] = 0.0f;
+    {
+      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      reinterpret_cast<float4 *>(S.coef)[lane] = zero4;
+      reinterpret_cast<float4 *>(S.coef)[64 + lane] = zero4;
+    }
     __syncthreads();
     const uint32_t header = S.words[0] >> 16;
     const int m0 = 2 - (int)((header >> 14) & 3), m1 = 2 - (int)((header >> 12) & 3), m2 = 3 - (int)((header >> 10) & 3);
     const int n = kAmounts[(header >> 5) & 7];
-    int wl = 0;
+    int wl = 0, sfi = 0;
     if (lane < n) {
       wl = (int)get_bits_be(S.words, 16 + 4 * lane, 4);
-      S.sfi[lane] = (uint8_t)get_bits_be(S.words, 16 + 4 * n + 6 * lane, 6);
+      sfi = (int)get_bits_be(S.words, 16 + 4 * n + 6 * lane, 6);
     }
-    if (lane < 52) S.wl[lane] = (uint8_t)wl;
-    const int mybits = (lane < n) ? wl_bits(wl) * (int)kSpecs[lane < 52 ? lane : 0] : 0;
+    const int mybits = wl_bits(wl) * my_size;
     int scan = mybits;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int o = __shfl_up(scan, d);
       if (lane >= d) scan += o;
     }
-    if (lane < 52) S.bit_off[lane] = 16 + 10 * n + scan - mybits;
+    if (lane < 52) S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
     __syncthreads();
     // ---------------- dequantizationStage (decoder.js:52-98) ----------------
+    const bool all_long = (m0 | m1 | m2) == 0;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int p = lane + 64 * m;
-      const int b = bfu_of_slot(p);
-      if (b >= n) continue;
-      const int w = S.wl[b];
-      if (w == 0) continue;
-      const int bits = w + 1, j = p - kBfuFirst[b];
-      const int s = S.sfi[b];
-      float v = 0.0f;
-      if (s != 0) {
-        const uint32_t raw = get_bits_be(S.words, S.bit_off[b] + j * bits, bits);
-        const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;   // bitstream.js:78-82
-        const int32_t range = (1 << (bits - 1)) - 1;
-        v = f32(((double)q * T->scale_factors[s]) / (double)range);                                   // quantization.js:74-76
-      }
-      const int mode = b >= 36 ? m2 : (b >= 20 ? m1 : m0);
-      S.coef[bfu_start(b, mode) + j] = v;
+      const uint32_t dsc = S.desc[slot_b[m]];
+      const int bits = dsc & 31;
+      if (bits == 0) continue;                                  // BFU not coded (or beyond nBfu: its word length reads 0)
+      const int sf = (dsc >> 5) & 63;
+      const uint32_t raw = get_bits_be(S.words, (int)(dsc >> 11) + slot_j[m] * bits, bits);
+      const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;     // bitstream.js:78-82
+      const int32_t range = (1 << (bits - 1)) - 1;
+      const float v = sf != 0 ? f32(((double)q * T->scale_factors[sf]) / (double)range) : 0.0f;   // quantization.js:65-78
+      const int mode = slot_b[m] >= 36 ? m2 : (slot_b[m] >= 20 ? m1 : m0);
+      S.coef[mode == 0 ? at_long[m] : at_short[m]] = v;
     }
     __syncthreads();
 
     // ---------------- imdctStage (decoder.js:116-330) ----------------
+    float *mid = S.u.m.mid;
+    if (all_long) {
+      float2 *z = S.u.m.zz.z;
+      imdct_pre(S.coef, T->mdct_inv256, lane, ig256a, z);
+      imdct_pre(S.coef + 128, T->mdct_inv256, lane, ig256b, z);
+      imdct_pre(S.coef + 256, T->mdct_inv512, lane, ig512a, z + 128);
+      imdct_pre(S.coef + 256, T->mdct_inv512, lane + 64, ig512b, z + 128);
+      __syncthreads();
+      fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
+      fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
+      fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
+      fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
+      fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
+      fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
+      fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
+      imdct_post<64>(z, ps0, T->mdct_inv256, lane, mid);
+      imdct_post<64>(z, ps1, T->mdct_inv256, lane, mid + 128);
+      imdct_post<128>(z + 128, ps0, T->mdct_inv512, lane, mid + 256);
+      imdct_post<128>(z + 128, ps1, T->mdct_inv512, lane + 64, mid + 256);
+      __syncthreads();
+      // overlap-add of the first 32 samples of every band (mdct.js:230-245 via decoder.js:203-232) ...
+      if (lane < 32) {
+        const bool lo = lane < 16;
+        const int i = lo ? lane : 31 - lane;
+        const double wa = T->window[i], wb = T->window[31 - i];       // w1 = W[i], w2 = W[31-i]
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+          const double pv = S.tail[16 * b + i], cv = mid[off + 15 - i];
+          S.band[off + lane] = lo ? f32(pv * wb - cv * wa) : f32(pv * wa + cv * wb);
+        }
+      }
+      // ... the rest of the band is invBuf[16 .. S-16) (decoder.js:215-221)
+      if (lane < 48) {
+        const int off = lane < 24 ? 0 : 128, q4 = lane < 24 ? lane : lane - 24;
+        *reinterpret_cast<float4 *>(&S.band[off + 32 + 4 * q4]) = *reinterpret_cast<const float4 *>(&mid[off + 16 + 4 * q4]);
+      }
+      if (lane < 56) *reinterpret_cast<float4 *>(&S.band[256 + 32 + 4 * lane]) = *reinterpret_cast<const float4 *>(&mid[256 + 16 + 4 * lane]);
+    } else {
     FrameModes M{m0, m1, m2};
-    float *re = S.u.m.re, *im = S.u.m.im, *mid = S.u.m.mid;
+    float *re = S.u.m.zz.ri.re, *im = S.u.m.zz.ri.im;
     // pre-twiddle (mdct.js:161-170), input un-reversed for bands 1,2
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -1472,7 +1557,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     for (int m = 0; m < 8; m++) {
       const int g = lane + 64 * m;
       const int b = g < 128 ? 0 : (g < 256 ? 1 : 2);
-      const int off = b == 0 ? 0 : (b == 1 ? 128 : 256), Sb = b == 2 ? 256 : 128;
+      const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
       const int l = g - off;
       const bool lng = M.mode_of_band(b) == 0;
       const int q = lng ? 0 : (l >> 5);            // block
@@ -1493,7 +1578,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
         v = mid[off + k - 16];                     // long block only: invBuf[16 .. S-16)
       }
       S.band[g] = v;
-      (void)Sb;
+    }
     }
     __syncthreads();
     if (lane < 48) {
