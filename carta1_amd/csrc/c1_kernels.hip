@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void imdct_post(const float2 *z, int slot, const __at
   dst[idx] = f32(i1);
 }
 
-__global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
   __shared__ DecodeLds S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
@@ -1397,14 +1397,12 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   for (int i = lane; i < 48; i += 64) S.tail[i] = 0.0f;
   if (lane < 3) S.words[53 + lane] = 0u;
   // lane-only geometry, computed once per wave
-  int slot_b[8], slot_j[8], at_long[8], at_short[8];
+  uint32_t slot[8];                                  // BFU(6) | index inside the BFU(5) << 6 | short-block position(9) << 11
 #pragma unroll
   for (int m = 0; m < 8; m++) {
-    const int p = lane0 + 64 * m;                    // coefficient slot in BFU-major order
-    slot_b[m] = bfu_of_slot(p);
-    slot_j[m] = p - kBfuFirst[slot_b[m]];
-    at_long[m] = kStartLong[slot_b[m]] + slot_j[m];
-    at_short[m] = kStartShort[slot_b[m]] + slot_j[m];
+    const int p = lane0 + 64 * m;                    // coefficient slot in BFU-major order (== long-block position)
+    const int b = bfu_of_slot(p), j = p - kBfuFirst[b];
+    slot[m] = (uint32_t)b | ((uint32_t)j << 6) | ((uint32_t)(kStartShort[b] + j) << 11);
   }
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
   const IPreGeometry ig256a = ipre_geometry<64, 6, false>(lane0, 0), ig256b = ipre_geometry<64, 6, true>(lane0, 64);
@@ -1453,16 +1451,17 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     const bool all_long = (m0 | m1 | m2) == 0;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const uint32_t dsc = S.desc[slot_b[m]];
+      const int sb = slot[m] & 63, sj = (slot[m] >> 6) & 31;
+      const uint32_t dsc = S.desc[sb];
       const int bits = dsc & 31;
       if (bits == 0) continue;                                  // BFU not coded (or beyond nBfu: its word length reads 0)
       const int sf = (dsc >> 5) & 63;
-      const uint32_t raw = get_bits_be(S.words, (int)(dsc >> 11) + slot_j[m] * bits, bits);
+      const uint32_t raw = get_bits_be(S.words, (int)(dsc >> 11) + sj * bits, bits);
       const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;     // bitstream.js:78-82
       const int32_t range = (1 << (bits - 1)) - 1;
       const float v = sf != 0 ? f32(((double)q * T->scale_factors[sf]) / (double)range) : 0.0f;   // quantization.js:65-78
-      const int mode = slot_b[m] >= 36 ? m2 : (slot_b[m] >= 20 ? m1 : m0);
-      S.coef[mode == 0 ? at_long[m] : at_short[m]] = v;
+      const int mode = sb >= 36 ? m2 : (sb >= 20 ? m1 : m0);
+      S.coef[mode == 0 ? lane + 64 * m : (int)(slot[m] >> 11)] = v;
     }
     __syncthreads();
 
