@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void imdct_post(const float2 *z, int slot, const __at
   dst[idx] = f32(i1);
 }
 
-__global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   __shared__ DecodeLds S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
@@ -1405,13 +1405,6 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
     slot[m] = (uint32_t)b | ((uint32_t)j << 6) | ((uint32_t)(kStartShort[b] + j) << 11);
   }
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
-  const IPreGeometry ig256a = ipre_geometry<64, 6, false>(lane0, 0), ig256b = ipre_geometry<64, 6, true>(lane0, 64);
-  const IPreGeometry ig512a = ipre_geometry<128, 7, true>(lane0, 0), ig512b = ipre_geometry<128, 7, true>(lane0 + 64, 0);
-  int fe1, fe2, fe4, fe8, fe16, fe32, fe64, fo1, fo2, fo4, fo8, fo16, fo32, fo64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
-  butterfly_geometry<1>(lane0, fe1, fo1, ft1); butterfly_geometry<2>(lane0, fe2, fo2, ft2); butterfly_geometry<4>(lane0, fe4, fo4, ft4);
-  butterfly_geometry<8>(lane0, fe8, fo8, ft8); butterfly_geometry<16>(lane0, fe16, fo16, ft16); butterfly_geometry<32>(lane0, fe32, fo32, ft32);
-  butterfly_geometry<64>(lane0, fe64, fo64, ft64);
-  const int ps0 = zsw(lane0), ps1 = zsw(64 + lane0);
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesDecode < L.frames) ? f0 + kRunFramesDecode : L.frames;
@@ -1468,6 +1461,13 @@ __global__ __launch_bounds__(C1_WAVE, 2) void k_decode(C1DecodeLaunch L) {
     // ---------------- imdctStage (decoder.js:116-330) ----------------
     float *mid = S.u.m.mid;
     if (all_long) {
+      const IPreGeometry ig256a = ipre_geometry<64, 6, false>(lane, 0), ig256b = ipre_geometry<64, 6, true>(lane, 64);
+      const IPreGeometry ig512a = ipre_geometry<128, 7, true>(lane, 0), ig512b = ipre_geometry<128, 7, true>(lane + 64, 0);
+      int fe1, fe2, fe4, fe8, fe16, fe32, fe64, fo1, fo2, fo4, fo8, fo16, fo32, fo64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
+      butterfly_geometry<1>(lane, fe1, fo1, ft1); butterfly_geometry<2>(lane, fe2, fo2, ft2); butterfly_geometry<4>(lane, fe4, fo4, ft4);
+      butterfly_geometry<8>(lane, fe8, fo8, ft8); butterfly_geometry<16>(lane, fe16, fo16, ft16); butterfly_geometry<32>(lane, fe32, fo32, ft32);
+      butterfly_geometry<64>(lane, fe64, fo64, ft64);
+      const int ps0 = zsw(lane), ps1 = zsw(64 + lane);
       float2 *z = S.u.m.zz.z;
       imdct_pre(S.coef, T->mdct_inv256, lane, ig256a, z);
       imdct_pre(S.coef + 128, T->mdct_inv256, lane, ig256b, z);
