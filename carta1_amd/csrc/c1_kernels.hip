@@ -1333,8 +1333,10 @@ struct alignas(16) DecodeLds {
   float tail[48];       // last 16 IMDCT samples per band (imdctOverlap tails, decoder.js:227-230)
   uint32_t words[56];   // the unit as big-endian words
   uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
-  alignas(16) float coef[512];
-  alignas(16) float band[512];
+  union alignas(16) {
+    float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
+    float band[512];    // reconstructed bands: born at the overlap-add
+  } cb;
   union alignas(16) {
     struct { union alignas(16) { struct { float re[256]; float im[256]; } ri; float2 z[256]; } zz; alignas(16) float mid[512]; } m;   // IMDCT
     struct { alignas(16) double w2[454]; } q2;                   // stage-2 synthesis work buffer (padded 2 per 4)
@@ -1419,8 +1421,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     if (lane < 53) S.words[lane] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane]);
     {
       const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      reinterpret_cast<float4 *>(S.coef)[lane] = zero4;
-      reinterpret_cast<float4 *>(S.coef)[64 + lane] = zero4;
+      reinterpret_cast<float4 *>(S.cb.coef)[lane] = zero4;
+      reinterpret_cast<float4 *>(S.cb.coef)[64 + lane] = zero4;
     }
     __syncthreads();
     const uint32_t header = S.words[0] >> 16;
@@ -1454,7 +1456,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       const int32_t range = (1 << (bits - 1)) - 1;
       const float v = sf != 0 ? f32(((double)q * T->scale_factors[sf]) / (double)range) : 0.0f;   // quantization.js:65-78
       const int mode = sb >= 36 ? m2 : (sb >= 20 ? m1 : m0);
-      S.coef[mode == 0 ? lane + 64 * m : (int)(slot[m] >> 11)] = v;
+      S.cb.coef[mode == 0 ? lane + 64 * m : (int)(slot[m] >> 11)] = v;
     }
     __syncthreads();
 
@@ -1469,10 +1471,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       butterfly_geometry<64>(lane, fe64, fo64, ft64);
       const int ps0 = zsw(lane), ps1 = zsw(64 + lane);
       float2 *z = S.u.m.zz.z;
-      imdct_pre(S.coef, T->mdct_inv256, lane, ig256a, z);
-      imdct_pre(S.coef + 128, T->mdct_inv256, lane, ig256b, z);
-      imdct_pre(S.coef + 256, T->mdct_inv512, lane, ig512a, z + 128);
-      imdct_pre(S.coef + 256, T->mdct_inv512, lane + 64, ig512b, z + 128);
+      imdct_pre(S.cb.coef, T->mdct_inv256, lane, ig256a, z);
+      imdct_pre(S.cb.coef + 128, T->mdct_inv256, lane, ig256b, z);
+      imdct_pre(S.cb.coef + 256, T->mdct_inv512, lane, ig512a, z + 128);
+      imdct_pre(S.cb.coef + 256, T->mdct_inv512, lane + 64, ig512b, z + 128);
       __syncthreads();
       fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
       fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
@@ -1495,15 +1497,15 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
         for (int b = 0; b < 3; b++) {
           const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
           const double pv = S.tail[16 * b + i], cv = mid[off + 15 - i];
-          S.band[off + lane] = lo ? f32(pv * wb - cv * wa) : f32(pv * wa + cv * wb);
+          S.cb.band[off + lane] = lo ? f32(pv * wb - cv * wa) : f32(pv * wa + cv * wb);
         }
       }
       // ... the rest of the band is invBuf[16 .. S-16) (decoder.js:215-221)
       if (lane < 48) {
         const int off = lane < 24 ? 0 : 128, q4 = lane < 24 ? lane : lane - 24;
-        *reinterpret_cast<float4 *>(&S.band[off + 32 + 4 * q4]) = *reinterpret_cast<const float4 *>(&mid[off + 16 + 4 * q4]);
+        *reinterpret_cast<float4 *>(&S.cb.band[off + 32 + 4 * q4]) = *reinterpret_cast<const float4 *>(&mid[off + 16 + 4 * q4]);
       }
-      if (lane < 56) *reinterpret_cast<float4 *>(&S.band[256 + 32 + 4 * lane]) = *reinterpret_cast<const float4 *>(&mid[256 + 16 + 4 * lane]);
+      if (lane < 56) *reinterpret_cast<float4 *>(&S.cb.band[256 + 32 + 4 * lane]) = *reinterpret_cast<const float4 *>(&mid[256 + 16 + 4 * lane]);
     } else {
     FrameModes M{m0, m1, m2};
     float *re = S.u.m.zz.ri.re, *im = S.u.m.zz.ri.im;
@@ -1520,7 +1522,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       const int i = (p - cbase) - q * nfft;
       const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_inv512 : T->mdct_inv256) : T->mdct_inv64;
       const int n2 = 2 * nfft;
-      const float *x = S.coef + obase + q * 32;
+      const float *x = S.cb.coef + obase + q * 32;
       const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
       const double r = -(double)(b > 0 ? x[n2 - 1 - j0] : x[j0]);
       const double mm = -(double)(b > 0 ? x[n2 - 1 - j1] : x[j1]);
@@ -1576,7 +1578,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       } else {
         v = mid[off + k - 16];                     // long block only: invBuf[16 .. S-16)
       }
-      S.band[g] = v;
+      S.cb.band[g] = v;
     }
     }
     __syncthreads();
@@ -1594,17 +1596,17 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const int j = 4 * lane + t;
-      hi4[t] = j < 39 ? S.dhi[j] : S.band[256 + j - 39];
+      hi4[t] = j < 39 ? S.dhi[j] : S.cb.band[256 + j - 39];
     }
     {
       float keep = 0.0f;
-      if (lane < 39) keep = S.band[256 + 217 + lane];
+      if (lane < 39) keep = S.cb.band[256 + 217 + lane];
       // stage 2: low + mid -> 256 samples (qmf.js:78-84 interleave)
       if (lane < 46) w2[pidx<2>(lane)] = S.d2[lane];
 #pragma unroll
       for (int d = 0; d < 2; d++) {
         const int i = 2 * lane + d;
-        const double l = S.band[i], h = S.band[128 + i];
+        const double l = S.cb.band[i], h = S.cb.band[128 + i];
         *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 2 * i)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
       }
       __syncthreads();
