@@ -44,8 +44,8 @@ struct C1DevEncOpts {
 
 // ---- geometry ------------------------------------------------------------------------------------
 constexpr int kRunFrames = 16;   // consecutive frames of one channel processed by one wave
-constexpr int kRunFramesDecode = 32; // consecutive units of one channel decoded by one wave
-constexpr int kRunFramesLong = 32;   // same, in the all-long-blocks fast path
+constexpr int kRunFramesDecode = 64; // consecutive units of one channel decoded by one wave
+constexpr int kRunFramesLong = 64;   // same, in the all-long-blocks fast path
 constexpr int kSideBytes = 64;   // per unit: sfi[52], modes byte, pad
 constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallback flag
 constexpr int kCandidateBytes = 8 * 8 + 8 * 32;  // per unit: 8 totals + 8 results (bit allocation scratch)

@@ -228,7 +228,6 @@ struct FrameModes {
 struct alignas(16) LongLds {
   double d1[46];                 // stage-1 QMF delay line
   double d2[46];                 // stage-2 QMF delay line
-  alignas(16) float band[512];   // low128 | mid128 | high256, raw
   alignas(16) float hbuf[296];   // delayed high band: [0,39) tail of the previous frame, [39,295) this frame
   alignas(4) uint8_t sfi[64];
   // scratch with disjoint lifetimes inside one frame (10 KiB per wave in total: 16 waves per CU)
@@ -240,7 +239,7 @@ struct alignas(16) LongLds {
         struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // MDCT inputs
         struct { alignas(16) float coef[512]; } c;                                                           // coefficients (after the pre-twiddle)
       } a;
-      union alignas(16) { float2 z[256]; } zz;                                                               // FFT points
+      union alignas(16) { float2 z[256]; float band[512]; } zz;   // FFT points; before the pre-twiddle: low128 | mid128 | high256, raw
     } m;
   } u;
 };
@@ -351,6 +350,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
   static_assert(!(DETECT && ALL_LONG), "detection decides the modes per frame");
   using Lds = typename std::conditional<ALL_LONG, LongLds, MixedLds>::type;
   __shared__ Lds S;
+  float *band_;                                        // low128 | mid128 | high256 of the current frame, raw
+  if constexpr (ALL_LONG) band_ = S.u.m.zz.band; else band_ = S.band;
   const C1DevEncOpts *O = L.opts;
   const int lane0 = threadIdx.x;
   int lane = lane0;
@@ -429,9 +430,9 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
     {
       double ev[2], od[2];
       if (!(L.debug & 16)) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
-      *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
-      *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
-      *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
+      *reinterpret_cast<float2 *>(&band_[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
+      *reinterpret_cast<float2 *>(&band_[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
+      *reinterpret_cast<float4 *>(&band_[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
       if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx<2>(256 + lane)];
     }
     __syncthreads();
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
     if (qmf_only) { __syncthreads(); continue; }
     if (emit && L.bands) {
       float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
-      const float4 *src = reinterpret_cast<const float4 *>(S.band);
+      const float4 *src = reinterpret_cast<const float4 *>(band_);
       dst[lane] = src[lane];
       dst[64 + lane] = src[64 + lane];
     }
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
       float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
       if (lane < 32) {
         const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
-        const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
+        const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
         nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
         if (emit) {
           in0[48 + lane] = ov0; in1[48 + lane] = ov1; in2[112 + lane] = ov2;     // overlap saved by the previous frame
@@ -477,10 +478,10 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
         }
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
         if (lane < 48) {
-          *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
-          *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+          *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[2 * lane]);
+          *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[128 + 2 * lane]);
         }
-        if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
+        if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
       __syncthreads();
       float2 *z = S.u.m.zz.z;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
           const int p = lane + 64 * m;
           const int base = p < 128 ? 0 : (p < 256 ? 128 : 256);
           const int lg = p < 256 ? 7 : 8;
-          re[base + bitrev(p - base, lg)] = S.band[p];
+          re[base + bitrev(p - base, lg)] = band_[p];
           im[p] = 0.0f;
         }
         __syncthreads();
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
         for (int i = lane; i < 96; i += 64) {
           const int b = i >> 5, k = i & 31;
           const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-          S.ovl[i] = f32(T->window[k] * (double)S.band[off + Sb - 32 + k]);
+          S.ovl[i] = f32(T->window[k] * (double)band_[off + Sb - 32 + k]);
         }
         __syncthreads();
         continue;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
         float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
         if (lane < 32) {
           const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
-          const double x0 = S.band[96 + lane], x1 = S.band[128 + 96 + lane], x2 = S.band[256 + 224 + lane];
+          const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
           nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
           if (emit) {
             in0[48 + lane] = S.ovl[lane]; in1[48 + lane] = S.ovl[32 + lane]; in2[112 + lane] = S.ovl[64 + lane];
@@ -664,10 +665,10 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
           }
           if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
           if (lane < 48) {
-            *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[2 * lane]);
-            *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&S.band[128 + 2 * lane]);
+            *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[2 * lane]);
+            *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[128 + 2 * lane]);
           }
-          if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.band[256 + 4 * lane]);
+          if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
         }
         __syncthreads();
         float2 *z = S.u.m.zz.z;
@@ -741,12 +742,12 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
               const int ws = b == 2 ? 112 : 48;
               const int x = l - ws - 32;
               if (l >= ws && l < ws + 32) v = S.ovl[32 * b + (l - ws)];
-              else if (x >= 0 && x < Sb - 32) v = S.band[off + x];
-              else if (x >= Sb - 32 && x < Sb) v = f32((double)S.band[off + x] * T->window[31 - (x - (Sb - 32))]);
+              else if (x >= 0 && x < Sb - 32) v = band_[off + x];
+              else if (x >= Sb - 32 && x < Sb) v = f32((double)band_[off + x] * T->window[31 - (x - (Sb - 32))]);
             } else {
               const int q = l >> 6, pos = l & 63;
-              if (pos < 32) v = q == 0 ? S.ovl[32 * b + pos] : f32(T->window[pos] * (double)S.band[off + 32 * (q - 1) + pos]);
-              else v = f32((double)S.band[off + 32 * q + (pos - 32)] * T->window[31 - (pos - 32)]);
+              if (pos < 32) v = q == 0 ? S.ovl[32 * b + pos] : f32(T->window[pos] * (double)band_[off + 32 * (q - 1) + pos]);
+              else v = f32((double)band_[off + 32 * q + (pos - 32)] * T->window[31 - (pos - 32)]);
             }
             in[g] = v;
           }
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
         for (int i = lane; i < 96; i += 64) {
           const int b = i >> 5, k = i & 31;
           const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-          S.ovl[i] = f32(T->window[k] * (double)S.band[off + Sb - 32 + k]);
+          S.ovl[i] = f32(T->window[k] * (double)band_[off + Sb - 32 + k]);
         }
 
         // pre-twiddle (mdct.js:76-105) straight into bit-reversed order
