@@ -146,6 +146,12 @@ class Context:
     def generate_device(self, signal, seed, frames, pcm_ptr):
         capi.check(capi.load().c1_generate_device(self._h, signal, seed, frames, C.c_void_p(pcm_ptr)))
 
+    def pcm_from_int_device(self, src_ptr, bits, channels, samples, pcm_ptrs):
+        capi.check(capi.load().c1_pcm_from_int_device(self._h, C.c_void_p(src_ptr), bits, channels, samples, capi.ptr_array(pcm_ptrs)))
+
+    def pcm_to_int16_device(self, pcm_ptrs, samples, dst_ptr):
+        capi.check(capi.load().c1_pcm_to_int16_device(self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), samples, C.c_void_p(dst_ptr)))
+
     def encode_stages_device(self, pcm_ptrs, frames, bands_ptr, coefs_ptr, side_ptr, alloc_ptr, options=None,
                              halo_frames=0):
         opts = (options or EncoderOptions()).to_c()

@@ -830,6 +830,50 @@ int c1_dec_stream_destroy(c1_dec_stream *s) {
   return C1_OK;
 }
 
+// ---- formats either side of the path ---------------------------------------------------------------------
+int c1_pcm_from_int_device(c1_ctx *ctx, const void *interleaved, int bits, int channels, int64_t samples_per_channel,
+                           float *const *pcm) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (bits != 16 && bits != 24 && bits != 32) return fail(C1_ERR_ARG, "bits must be 16, 24 or 32, got %d", bits);
+  if (samples_per_channel < 0) return fail(C1_ERR_ARG, "samples_per_channel must be >= 0");
+  if (samples_per_channel == 0) return C1_OK;
+  if (!interleaved || !pcm || !pcm[0] || (channels == 2 && !pcm[1])) return fail(C1_ERR_ARG, "NULL buffer");
+  c1k_launch_pcm_from_int(interleaved, bits, channels, samples_per_channel, pcm, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+int c1_pcm_to_int16_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t samples_per_channel,
+                           int16_t *interleaved) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (samples_per_channel < 0) return fail(C1_ERR_ARG, "samples_per_channel must be >= 0");
+  if (samples_per_channel == 0) return C1_OK;
+  if (!interleaved || !pcm || !pcm[0] || (channels == 2 && !pcm[1])) return fail(C1_ERR_ARG, "NULL buffer");
+  if (channels == 2 && ((uintptr_t)interleaved & 3)) return fail(C1_ERR_ARG, "stereo int16 output must be 4-byte aligned");
+  c1k_launch_pcm_to_int16(pcm, channels, samples_per_channel, interleaved, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+int c1_aea_header(const char *title, uint32_t unit_count, int channels, uint8_t out[2048]) {
+  if (!out) return fail(C1_ERR_ARG, "out is NULL");
+  memset(out, 0, 2048);
+  out[0] = 0x00; out[1] = 0x08; out[2] = 0x00; out[3] = 0x00;          // AEA_MAGIC
+  if (title) {
+    size_t n = strlen(title);
+    if (n > 255) n = 255;                                               // AEA_TITLE_SIZE - 1
+    memcpy(out + 4, title, n);
+  }
+  out[260] = (uint8_t)unit_count; out[261] = (uint8_t)(unit_count >> 8);
+  out[262] = (uint8_t)(unit_count >> 16); out[263] = (uint8_t)(unit_count >> 24);
+  out[264] = (uint8_t)channels;
+  return C1_OK;
+}
+
 // ---- synthetic input ----------------------------------------------------------------------------------
 int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, float *pcm) {
   int rc = ctx_bind(ctx);

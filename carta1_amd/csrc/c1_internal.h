@@ -85,3 +85,5 @@ void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream);
 void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream);
+void c1k_launch_pcm_from_int(const void *src, int bits, int channels, int64_t n, float *const *pcm, hipStream_t stream);
+void c1k_launch_pcm_to_int16(const float *const *pcm, int channels, int64_t n, int16_t *dst, hipStream_t stream);

@@ -142,6 +142,19 @@ enum { C1_SIGNAL_WHITE = 0, C1_SIGNAL_PINK_BURSTS = 1 };
  * in BASELINE.md section 4 exactly (the parity subset). */
 int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, float *pcm);
 
+/* ---- the data formats either side of the path -------------- */
+/* WAV PCM ingest, bin/cli.js:367-404 (WavReader._processFrameBuffer / _sampleToFloat): little-endian
+ * interleaved integer PCM (bits = 16, 24 or 32) -> planar float32, value / 2^(bits-1).  Device pointers. */
+int c1_pcm_from_int_device(c1_ctx *ctx, const void *interleaved, int bits, int channels,
+                           int64_t samples_per_channel, float *const *pcm);
+/* 16-bit WAV output, codec/io/processor.js:368-447: clamp to [-1,1], negative * 32768, positive * 32767,
+ * DataView.setInt16 truncation; planar float32 -> little-endian interleaved int16.  Device pointers. */
+int c1_pcm_to_int16_device(c1_ctx *ctx, const float *const *pcm, int channels,
+                           int64_t samples_per_channel, int16_t *interleaved);
+/* AeaFile.createHeader, codec/io/serialization.js:190-211 (host side; the units a batch call returns are
+ * already the AEA body: header + units is the whole file).  title is UTF-8, truncated to 255 bytes. */
+int c1_aea_header(const char *title, uint32_t unit_count, int channels, uint8_t out[2048]);
+
 /* ---- stage taps for bring-up and stage-level parity tests (device pointers) ---------------- */
 /* bands: frames*channels*512 floats (low128|mid128|high256 per unit index, before windowing);
  * coefs: same shape (MDCT coefficients as quantizationStage receives them);

@@ -717,3 +717,50 @@ void c1o_gen_pinkT(uint32_t seed, long n, float *out) {
     out[i] = F32(v);
   }
 }
+
+/* ---- formats either side of the path ------------------------------------------------------- */
+
+/* bin/cli.js:367-404: DataView.getInt16/getInt32 little endian; 24-bit assembled from three bytes with the
+ * sign fix `if (sample & 0x800000) sample |= ~0xffffff`; result / 2^(bits-1) stored into a Float32Array */
+void c1o_pcm_from_int(const uint8_t *src, int bits, int channels, long samples, float *const *pcm) {
+  const int bps = bits / 8;
+  for (long i = 0; i < samples; i++)
+    for (int c = 0; c < channels; c++) {
+      const uint8_t *p = src + (i * channels + c) * bps;
+      double v;
+      if (bits == 16) v = (double)(int16_t)(uint16_t)(p[0] | (p[1] << 8)) / 32768.0;
+      else if (bits == 24) {
+        int32_t s = p[0] | (p[1] << 8) | (p[2] << 16);
+        if (s & 0x800000) s |= ~0xffffff;
+        v = (double)s / 8388608.0;
+      } else {
+        v = (double)(int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) / 2147483648.0;
+      }
+      pcm[c][i] = (float)v;
+    }
+}
+
+/* processor.js:381-389: Math.max(-1, Math.min(1, x)) (NaN propagates), then x<0 ? x*0x8000 : x*0x7fff,
+ * DataView.setInt16 = ToInt16 (NaN -> 0, truncation toward zero; the clamped value is always in range) */
+static int16_t wav_sample(float x) {
+  double s = (double)x;
+  if (isnan(s)) return 0;
+  s = s > 1.0 ? 1.0 : s;
+  s = s < -1.0 ? -1.0 : s;
+  const double v = s < 0 ? s * 32768.0 : s * 32767.0;
+  return (int16_t)(int32_t)v;
+}
+void c1o_pcm_to_int16(const float *const *pcm, int channels, long samples, int16_t *out) {
+  for (long i = 0; i < samples; i++)
+    for (int c = 0; c < channels; c++) out[i * channels + c] = wav_sample(pcm[c][i]);
+}
+
+void c1o_aea_header(const char *title, uint32_t frame_count, int channels, uint8_t out[2048]) {
+  memset(out, 0, 2048);
+  out[1] = 0x08;                                        /* AEA_MAGIC 00 08 00 00, constants.js:11 */
+  size_t n = title ? strlen(title) : 0;
+  if (n > 255) n = 255;                                 /* AEA_TITLE_SIZE - 1 */
+  if (n) memcpy(out + 4, title, n);
+  for (int k = 0; k < 4; k++) out[260 + k] = (uint8_t)(frame_count >> (8 * k));
+  out[264] = (uint8_t)channels;
+}

@@ -97,6 +97,14 @@ void c1o_decode_stream(const uint8_t *units, int channels, long frames,
 void c1o_gen_white(uint32_t seed, long n, float *out);
 void c1o_gen_pinkT(uint32_t seed, long n, float *out);
 
+/* formats either side of the path */
+/* WavReader._sampleToFloat, bin/cli.js:394-404: interleaved LE int16/24/32 -> planar float32 */
+void c1o_pcm_from_int(const uint8_t *interleaved, int bits, int channels, long samples, float *const *pcm);
+/* _createMonoWavBlob/_createStereoWavBlob sample loops, codec/io/processor.js:379-392,429-447 */
+void c1o_pcm_to_int16(const float *const *pcm, int channels, long samples, int16_t *interleaved);
+/* AeaFile.createHeader, codec/io/serialization.js:190-211 */
+void c1o_aea_header(const char *title, uint32_t frame_count, int channels, uint8_t out[2048]);
+
 #ifdef __cplusplus
 }
 #endif

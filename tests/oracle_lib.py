@@ -75,6 +75,9 @@ def lib():
                                            C.POINTER(fp)]
         _lib.c1o_gen_white.argtypes = [C.c_uint32, C.c_long, fp]
         _lib.c1o_gen_pinkT.argtypes = [C.c_uint32, C.c_long, fp]
+        _lib.c1o_pcm_from_int.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_long, C.POINTER(fp)]
+        _lib.c1o_pcm_to_int16.argtypes = [C.POINTER(fp), C.c_int, C.c_long, C.POINTER(C.c_int16)]
+        _lib.c1o_aea_header.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint8)]
     return _lib
 
 
@@ -130,6 +133,31 @@ def make_options(fixed_modes=None, bias=1.0, threshold=1.0):
     for i in range(64):
         o.biased_sf[i] = b[i]
     return o
+
+
+def pcm_from_int(raw, bits, channels):
+    """raw: uint8 array of interleaved little-endian integer PCM.  Returns planar float32 arrays."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    n = len(raw) // (channels * (bits // 8))
+    outs = [np.empty(n, dtype=np.float32) for _ in range(channels)]
+    ptrs = (C.POINTER(C.c_float) * channels)(*[_fp(o) for o in outs])
+    lib().c1o_pcm_from_int(_u8(raw), bits, channels, n, ptrs)
+    return outs
+
+
+def pcm_to_int16(channels):
+    chans = [np.ascontiguousarray(c, dtype=np.float32) for c in channels]
+    n = len(chans[0])
+    out = np.empty(n * len(chans), dtype=np.int16)
+    ptrs = (C.POINTER(C.c_float) * len(chans))(*[_fp(c) for c in chans])
+    lib().c1o_pcm_to_int16(ptrs, len(chans), n, out.ctypes.data_as(C.POINTER(C.c_int16)))
+    return out
+
+
+def aea_header(title, frame_count, channels):
+    out = np.zeros(2048, dtype=np.uint8)
+    lib().c1o_aea_header(title.encode('utf-8'), frame_count, channels, _u8(out))
+    return out.tobytes()
 
 
 def gen_white(seed, n):

@@ -115,6 +115,11 @@ def test_aea_header_matches_reference_bytes():
     assert len(h) == e['header_len'] == 2048
     assert h[:272].hex() == e['header_hex_first_272']
     assert c1.parse_aea_header(h) == {'title': 'encoded by carta1', 'frameCount': 4, 'channelCount': 2}
+    # the C entry point (host only, no device needed) writes the same bytes
+    from carta1_amd import capi
+    buf = (C.c_uint8 * 2048)()
+    assert capi.load().c1_aea_header(b'encoded by carta1', 4, 2, buf) == 0
+    assert bytes(buf) == h
     with pytest.raises(ValueError, match='Invalid AEA file'):
         c1.parse_aea_header(bytes(2048))
     with pytest.raises(ValueError, match='Header must be 2048 bytes'):

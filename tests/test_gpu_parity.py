@@ -270,3 +270,80 @@ def test_device_generator_matches_host_generator(ctx):
     want = O.gen_pinkT(3, 512 * 512)
     assert np.array_equal(got[:512 * 512].view(np.uint32), want.view(np.uint32))   # segment 0 == BASELINE generator
     assert np.isfinite(got).all() and got[512 * 512:].std() > 0.01
+
+
+# ---- formats either side of the path: WAV PCM <-> planar float32 on the device --------------
+
+def test_wav16_output_matches_reference_blob_and_oracle(ctx):
+    import torch
+    w = json.load(open(os.path.join(G, 'wav16.json')))
+    L = np.frombuffer(bytes.fromhex(w['left_f32']), dtype='<f4').copy()
+    R = np.frombuffer(bytes.fromhex(w['right_f32']), dtype='<f4').copy()
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.zeros(len(L), dtype=torch.int16, device='cuda')
+    ctx.pcm_to_int16_device([dl.data_ptr()], len(L), out.data_ptr())
+    ctx.synchronize()
+    assert out.cpu().numpy().astype('<i2').tobytes().hex() == w['mono_i16']
+    out2 = torch.zeros(2 * len(L), dtype=torch.int16, device='cuda')
+    ctx.pcm_to_int16_device([dl.data_ptr(), dr.data_ptr()], len(L), out2.data_ptr())
+    ctx.synchronize()
+    assert out2.cpu().numpy().astype('<i2').tobytes().hex() == w['stereo_i16']
+    # every float32 bit pattern class at scale: 4M random bit patterns (NaNs, infinities, denormals included)
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 1 << 32, size=1 << 22, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    dx = torch.from_numpy(x.copy()).cuda()
+    o = torch.zeros(len(x), dtype=torch.int16, device='cuda')
+    ctx.pcm_to_int16_device([dx.data_ptr()], len(x), o.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(o.cpu().numpy(), O.pcm_to_int16([x]))
+
+
+@pytest.mark.parametrize('bits,ch', [(16, 1), (16, 2), (24, 1), (24, 2), (32, 1), (32, 2)])
+def test_wav_ingest_matches_oracle(ctx, bits, ch):
+    import torch
+    rng = np.random.default_rng(bits * 3 + ch)
+    n = 100003                                           # odd length: no alignment assumptions
+    raw = rng.integers(0, 256, size=n * ch * (bits // 8), dtype=np.uint8)
+    raw[:bits // 8] = [0] * (bits // 8 - 1) + [0x80]     # most negative sample -> exactly -1
+    want = O.pcm_from_int(raw, bits, ch)
+    d = torch.from_numpy(raw).cuda()
+    outs = [torch.zeros(n, dtype=torch.float32, device='cuda') for _ in range(ch)]
+    ctx.pcm_from_int_device(d.data_ptr(), bits, ch, n, [o.data_ptr() for o in outs])
+    ctx.synchronize()
+    for c in range(ch):
+        assert np.array_equal(outs[c].cpu().numpy().view(np.uint32), want[c].view(np.uint32))
+    assert want[0][0] == -1.0
+    # unaligned input / output pointers take the scalar kernel: same answer
+    bps = bits // 8
+    d1 = torch.zeros(len(raw) + 1, dtype=torch.uint8, device='cuda')
+    d1[1:] = d
+    outs1 = [torch.zeros(n + 1, dtype=torch.float32, device='cuda') for _ in range(ch)]
+    ctx.pcm_from_int_device(d1.data_ptr() + 1, bits, ch, n, [o.data_ptr() + 4 for o in outs1])
+    ctx.synchronize()
+    for c in range(ch):
+        assert np.array_equal(outs1[c][1:].cpu().numpy().view(np.uint32), want[c].view(np.uint32))
+        assert outs1[c][0].item() == 0.0
+
+
+def test_wav16_file_to_aea_to_wav16_device_chain(ctx):
+    """int16 WAV body -> planar f32 -> units -> f32 -> int16, all on the device, against the oracle chain."""
+    import torch
+    import carta1_amd as c1
+    n = 64 * 512
+    pcm16 = (np.stack([O.gen_white(21, n), O.gen_white(22, n)], axis=1) * 20000).astype('<i2')
+    raw = torch.from_numpy(pcm16.reshape(-1).view(np.uint8).copy()).cuda()
+    chans = [torch.zeros(n, dtype=torch.float32, device='cuda') for _ in range(2)]
+    ctx.pcm_from_int_device(raw.data_ptr(), 16, 2, n, [c.data_ptr() for c in chans])
+    units = torch.zeros(64 * 2 * 212, dtype=torch.uint8, device='cuda')
+    ctx.encode_device([c.data_ptr() for c in chans], 64, units.data_ptr(), c1.EncoderOptions())
+    back = [torch.zeros(n, dtype=torch.float32, device='cuda') for _ in range(2)]
+    ctx.decode_device(units.data_ptr(), 2, 64, [b.data_ptr() for b in back])
+    out = torch.zeros(2 * n, dtype=torch.int16, device='cuda')
+    ctx.pcm_to_int16_device([b.data_ptr() for b in back], n, out.data_ptr())
+    ctx.synchronize()
+    f = O.pcm_from_int(pcm16.reshape(-1).view(np.uint8), 16, 2)
+    u, _ = O.encode_stream(f)
+    p, _ = O.decode_stream(u, 2)
+    assert np.array_equal(units.cpu().numpy().reshape(-1, 212), u)
+    assert np.array_equal(out.cpu().numpy(), O.pcm_to_int16(p))
