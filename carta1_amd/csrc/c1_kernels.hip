@@ -38,6 +38,14 @@ __device__ __forceinline__ int lane_for_this_frame(int lane) {
   asm volatile("" : "+v"(lane));
   return lane;
 }
+// Always true, but not to the compiler: `if (own_block()) core(); else cheap();` keeps a long unrolled core in a
+// basic block of its own.  Merged into the surrounding block, the scheduler hoists the core's LDS reads over
+// the code before it and the kernel spills (k_analysis_fast: 110 VGPRs and no scratch with, 128 + 49 spills without).
+__device__ __forceinline__ bool own_block() {
+  int one = 1;
+  asm volatile("" : "+s"(one));
+  return one != 0;
+}
 __device__ __forceinline__ TablesPtr tables_for_this_frame(const C1DevTables *p) {
   unsigned long long v = (unsigned long long)p;
   asm volatile("" : "+s"(v));
@@ -239,7 +247,7 @@ struct alignas(16) LongLds {
         struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // MDCT inputs
         struct { alignas(16) float coef[512]; } c;                                                           // coefficients (after the pre-twiddle)
       } a;
-      union alignas(16) { float2 z[256]; float band[512]; } zz;   // FFT points; before the pre-twiddle: low128 | mid128 | high256, raw
+      union alignas(16) { float2 z[320]; float band[512]; } zz;   // FFT points (4 pad per 16); before the pre-twiddle: low128 | mid128 | high256, raw
     } m;
   } u;
 };
@@ -263,7 +271,7 @@ struct alignas(16) MixedLds {
         struct { alignas(16) float coef[512]; } c;
       } a;
       union alignas(16) {
-        float2 z[256];
+        float2 z[320];
         struct { float re[256]; float im[256]; } ri;
       } zz;
     } m;
@@ -272,7 +280,7 @@ struct alignas(16) MixedLds {
   } u;
 };
 
-// one radix-2 butterfly (fft.js:46-60) on interleaved points; H = half stride (compile time)
+// (decoder) one radix-2 butterfly (fft.js:46-60) on interleaved points; H = half stride (compile time)
 // Where logical point j (0..127) of a 128-point region lives in LDS: a GF(2)-linear permutation found by
 // search (tools/lds_model.py) that makes the bit-reversed pre-twiddle stores, all seven butterfly stages
 // and the post-twiddle loads close to bank-conflict free (model cost 188 vs 364 for the identity).
@@ -304,45 +312,162 @@ __device__ __forceinline__ void fft_butterfly(float2 *z, int pe, int po, int tw,
   z[po] = make_float2(f32(er - xr), f32(ei - xi));
 }
 
-// pre-twiddle of complex point k of an N-point MDCT (mdct.js:76-105), N4 = N/4, written bit-reversed
-// The five indices and the sign mask depend on the lane only: PreGeometry is filled once per wave.
-struct PreGeometry { int ia, ib, ic, id, zi; uint32_t sign; };
-template <int N4, int LG>
-__device__ __forceinline__ PreGeometry pre_geometry(int k, int region_offset) {
-  const int i = 2 * k;
-  const bool lo = i < N4;
-  PreGeometry g;
-  g.ia = 3 * N4 - 1 - i;
-  g.ic = N4 + i;
-  g.ib = lo ? 3 * N4 + i : i - N4;
-  g.id = lo ? N4 - 1 - i : 5 * N4 - 1 - i;
-  g.sign = lo ? 0u : 0x80000000u;       // second half: r = a - b, m = c + d
-  g.zi = zsw(region_offset + bitrev(k, LG));
-  return g;
-}
-__device__ __forceinline__ void mdct_pre(const float *in, const __attribute__((address_space(4))) double *tab, int i,
-                                         const PreGeometry &g, float2 *z) {
-  const float a = in[g.ia];
-  const float c = in[g.ic];
-  const float b = __uint_as_float(__float_as_uint(in[g.ib]) ^ g.sign);
-  const float d = __uint_as_float(__float_as_uint(in[g.id]) ^ g.sign);
-  const double r = (double)a + (double)b;
-  const double mm = (double)c - (double)d;
-  const double cs = tab[i], sn = tab[i + 1];
-  z[g.zi] = make_float2(f32(r * cs + mm * sn), f32(mm * cs - r * sn));
+// ---- long-block MDCT core, radix-4 rounds -------------------------------------------------------------
+// The three long transforms of a frame (64, 64 and 128 complex points) run side by side: lanes 0..15 own
+// band 0, 16..31 band 1, 32..63 band 2, four points per lane.  The reference's radix-2 stages (fft.js:41-66)
+// are executed two at a time in registers -- same operations, same Float32 rounding after every stage, same
+// tabulated twiddles -- so a frame makes 3 (4 for the 128-point transform) trips through LDS instead of 9:
+//   round A  pre-twiddle (mdct.js:76-105) of the points at bit-reversed positions 4g..4g+3, stages h = 1, 2
+//   round B  stages h = 4, 8       (positions p + 4j inside one 16-block)
+//   round C  stages h = 16, 32     (positions p + 16j)
+//   round D  stage  h = 64         (band 2 only: positions m, m + 64)
+//   post-twiddle (mdct.js:110-119) + spectrum reversal straight from the registers of the last round.
+// A point at position p of band b lives in slot zslot(base_b + p): 4 pad slots after every 16 keep every
+// exchange "lane base + immediate offset" and free of bank conflicts (tools/lds_model.py).
+__device__ __forceinline__ int zslot(int pos) { return pos + 4 * (pos >> 4); }
+
+struct R4Geometry {
+  int ia[4], ic[4], ib0, id0, ib3, id3;   // float indices into in0|in1|in2 of the pre-twiddle operands
+  int pre_tab[4];                          // byte offset (from the tables) of (cos,sin) of point k_j
+  int za, zb, zc, zd;                      // first slot of the lane's points in rounds A..D
+  int twb, twc, twd;                       // byte offset of the lane's first twiddle in rounds B..D
+  int post_tab[4];
+  int cx[4], cy[4];                        // coefficient index of the two outputs of each final point
+  bool band2;
+};
+
+__device__ __forceinline__ R4Geometry r4_geometry(int lane) {
+  R4Geometry G;
+  const int band = lane < 16 ? 0 : (lane < 32 ? 1 : 2);
+  const int g = lane - (band == 0 ? 0 : (band == 1 ? 16 : 32));
+  const int n4 = band == 2 ? 128 : 64, q = n4 / 4;
+  const int r = bitrev(g, band == 2 ? 5 : 4);
+  const int in_base = band == 0 ? 0 : (band == 1 ? 256 : 512);
+  const int tab_base = band == 2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256);
+  const int tw_base = (int)offsetof(C1DevTables, fft_tw);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int jp = ((j & 1) << 1) | (j >> 1);       // position 4g+j holds point k = r + q * bitrev2(j)
+    const int k = r + q * jp, i = 2 * k;
+    G.ia[j] = in_base + 3 * n4 - 1 - i;
+    G.ic[j] = in_base + n4 + i;
+    G.pre_tab[j] = tab_base + 16 * k;
+  }
+  G.ib0 = in_base + 3 * n4 + 2 * r;                 // j = 0: first half (i < N/4)
+  G.id0 = in_base + n4 - 1 - 2 * r;
+  const int i3 = 2 * (r + 3 * q);                   // j = 3: second half
+  G.ib3 = in_base + i3 - n4;
+  G.id3 = in_base + 5 * n4 - 1 - i3;
+  const int pbase = band == 0 ? 0 : (band == 1 ? 64 : 128);
+  G.za = zslot(pbase + 4 * g);
+  G.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
+  G.twb = tw_base + 16 * (3 + (g & 3));
+  G.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
+  G.twc = tw_base + 16 * (15 + (g & 15));
+  G.band2 = band == 2;
+  G.zd = zslot(128 + (g & 31));
+  G.twd = tw_base + 16 * (63 + (g & 31));
+  const int cbase = band == 0 ? 0 : (band == 1 ? 128 : 256), n2 = 2 * n4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    // final points: bands 0/1 hold g + 16j after round C; band 2 holds g, g+64, g+32, g+96 after round D
+    const int i = band == 2 ? g + (j == 1 ? 64 : (j == 2 ? 32 : (j == 3 ? 96 : 0))) : g + 16 * j;
+    G.post_tab[j] = tab_base + 16 * i;
+    const int e0 = cbase + 2 * i, e1 = cbase + n2 - 1 - 2 * i;
+    G.cx[j] = band == 0 ? e0 : e1;                  // bands 1 and 2 are stored reversed (utils.js:42-48)
+    G.cy[j] = band == 0 ? e1 : e0;
+  }
+  return G;
 }
 
-// post-twiddle (mdct.js:110-119) of point i; REV = spectrum reversal of bands 1,2 (utils.js:42-48)
-template <int NFFT, bool REV>
-__device__ __forceinline__ void mdct_post(const float2 *z, int slot, const __attribute__((address_space(4))) double *tab, int i,
-                                          float *dst) {
-  const float2 zz = z[slot];
-  const double cs = tab[2 * i], sn = tab[2 * i + 1], rr = zz.x, ii = zz.y;
-  const float o0 = f32(-rr * cs - ii * sn);
-  const float o1 = f32(-rr * sn + ii * cs);
-  constexpr int n2 = 2 * NFFT;
-  if (REV) { dst[n2 - 1 - 2 * i] = o0; dst[2 * i] = o1; }
-  else { dst[2 * i] = o0; dst[n2 - 1 - 2 * i] = o1; }
+// lane-varying table reads go through a buffer resource: 32-bit byte offsets (one VGPR per address; the
+// 64-bit form costs two plus an add) and hardware bounds checking against the table size
+typedef __amdgpu_buffer_rsrc_t TablesRsrc;
+__device__ __forceinline__ TablesRsrc tables_rsrc(const C1DevTables *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<C1DevTables *>(p), 0, (int)sizeof(C1DevTables), 0x00020000);
+}
+__device__ __forceinline__ double2 table_pair(TablesRsrc R, int byte_offset) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(R, byte_offset, 0, 0);
+  double2 d;
+  __builtin_memcpy(&d, &v, sizeof d);
+  return d;
+}
+// one radix-2 butterfly of fft.js:46-60 on Float32 points held in registers
+__device__ __forceinline__ void r2_butterfly(float2 &e, float2 &o, const double2 w) {
+  const double er = e.x, ei = e.y, orr = o.x, oi = o.y;
+  const double xr = orr * w.x - oi * w.y;
+  const double xi = orr * w.y + oi * w.x;
+  e = make_float2(f32(er + xr), f32(ei + xi));
+  o = make_float2(f32(er - xr), f32(ei - xi));
+}
+
+// in: 1024 floats (in0 | in1 | in2, zero padded long-block inputs); z: 320 slots; coef: 512 floats (may share
+// memory with `in`: the inputs are dead once round A has read them)
+__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R) {
+  float2 x[4];
+  // ---- round A: pre-twiddle + stages 1, 2 ----
+  {
+    const float a0 = in[G.ia[0]], c0 = in[G.ic[0]], b0 = in[G.ib0], d0 = in[G.id0];
+    const float a1 = in[G.ia[1]], c1 = in[G.ic[1]];
+    const float a2 = in[G.ia[2]], c2 = in[G.ic[2]];
+    const float a3 = in[G.ia[3]], c3 = in[G.ic[3]], b3 = in[G.ib3], d3 = in[G.id3];
+    const double2 t0 = table_pair(R, G.pre_tab[0]), t1 = table_pair(R, G.pre_tab[1]);
+    const double2 t2 = table_pair(R, G.pre_tab[2]), t3 = table_pair(R, G.pre_tab[3]);
+    // the long-block input is zero outside [N/4 - 16 .. 3N/4 + 16): for the points of positions 4g+1 and 4g+2
+    // the operands b and d are those zeros for every lane, and x - (+0) == x, so only "+ 0.0" remains
+    const double r0 = (double)a0 + (double)b0, m0 = (double)c0 - (double)d0;      // first half:  r = a + b, m = c - d
+    const double r1 = (double)a1, m1 = (double)c1 + 0.0;                          // second half: r = a - b, m = c + d
+    const double r2 = (double)a2 + 0.0, m2 = (double)c2;
+    const double r3 = (double)a3 - (double)b3, m3 = (double)c3 + (double)d3;
+    x[0] = make_float2(f32(r0 * t0.x + m0 * t0.y), f32(m0 * t0.x - r0 * t0.y));
+    x[1] = make_float2(f32(r1 * t1.x + m1 * t1.y), f32(m1 * t1.x - r1 * t1.y));
+    x[2] = make_float2(f32(r2 * t2.x + m2 * t2.y), f32(m2 * t2.x - r2 * t2.y));
+    x[3] = make_float2(f32(r3 * t3.x + m3 * t3.y), f32(m3 * t3.x - r3 * t3.y));
+    const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]);
+    const double2 w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
+    const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]);
+    r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0);
+    r2_butterfly(x[0], x[2], w1); r2_butterfly(x[1], x[3], w2);
+    float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+    dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+    dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+  }
+  __syncthreads();
+  // ---- round B: stages 4, 8 ----
+  {
+    float2 *p = z + G.zb;
+    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
+    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+    r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+    p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3];
+  }
+  __syncthreads();
+  // ---- round C: stages 16, 32 ----
+  {
+    float2 *p = z + G.zc;
+    const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
+    x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
+    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+    r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+    if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
+  }
+  __syncthreads();
+  // ---- round D: stage 64 of the 128-point transform ----
+  if (G.band2) {
+    const float2 *p = z + G.zd;
+    const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);
+    x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
+    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wb);
+  }
+  // ---- post-twiddle + spectrum reversal ----
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double2 t = table_pair(R, G.post_tab[j]);
+    const double rr = x[j].x, ii = x[j].y;
+    coef[G.cx[j]] = f32(-rr * t.x - ii * t.y);
+    coef[G.cy[j]] = f32(-rr * t.y + ii * t.x);
+  }
 }
 
 template <bool DETECT, bool ALL_LONG>
@@ -369,14 +494,9 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
   int cur = 0;                                           // which half of S.mag is "current"
   double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;   // lane b < 3: features of the previous frame, band b
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
-  // lane-only geometry of the MDCT core, computed once (everything else is re-derived per frame)
-  const PreGeometry g256a = pre_geometry<64, 6>(lane0, 0), g256b = pre_geometry<64, 6>(lane0, 64);
-  const PreGeometry g512a = pre_geometry<128, 7>(lane0, 0), g512b = pre_geometry<128, 7>(lane0 + 64, 0);
-  int fe1, fe2, fe4, fe8, fe16, fe32, fe64, fo1, fo2, fo4, fo8, fo16, fo32, fo64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
-  butterfly_geometry<1>(lane0, fe1, fo1, ft1); butterfly_geometry<2>(lane0, fe2, fo2, ft2); butterfly_geometry<4>(lane0, fe4, fo4, ft4);
-  butterfly_geometry<8>(lane0, fe8, fo8, ft8); butterfly_geometry<16>(lane0, fe16, fo16, ft16); butterfly_geometry<32>(lane0, fe32, fo32, ft32);
-  butterfly_geometry<64>(lane0, fe64, fo64, ft64);
-  const int ps0 = zsw(lane0), ps1 = zsw(64 + lane0);     // post-twiddle slots of points lane and lane+64
+  // lane-only geometry of the long-block MDCT core, computed once (everything else is re-derived per frame)
+  const R4Geometry G4 = r4_geometry(lane0);
+  const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
@@ -414,7 +534,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
     __syncthreads();
     {
       double ev[4], od[4];
-      if (!(L.debug & 16)) qmf_analysis_core<4, 3>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
+      if (own_block()) qmf_analysis_core<4, 3>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
       double *w2 = S.u.q2.w2;
       if (lane < 46) { w2[pidx<2>(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx<3>(512 + lane)]; }
       float lo[4];
@@ -429,7 +549,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
     __syncthreads();
     {
       double ev[2], od[2];
-      if (!(L.debug & 16)) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
+      if (own_block()) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
       *reinterpret_cast<float2 *>(&band_[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
       *reinterpret_cast<float2 *>(&band_[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
       *reinterpret_cast<float4 *>(&band_[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
@@ -484,31 +604,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
       __syncthreads();
-      float2 *z = S.u.m.zz.z;
-      if (!(L.debug & 32)) {
-      mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256a, z);
-      mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256b, z);
-      mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
-      mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
-      }
-      __syncthreads();
-      // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
-      if (!(L.debug & 8)) {
-      fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
-      fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
-      fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
-      fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
-      fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
-      fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
-      fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
-      }
       float *coef = S.u.m.a.c.coef;
-      if (!(L.debug & 32)) {
-      mdct_post<64, false>(z, ps0, T->mdct_fwd256, lane, coef);
-      mdct_post<64, true>(z, ps1, T->mdct_fwd256, lane, coef + 128);
-      mdct_post<128, true>(z + 128, ps0, T->mdct_fwd512, lane, coef + 256);
-      mdct_post<128, true>(z + 128, ps1, T->mdct_fwd512, lane + 64, coef + 256);
-      }
+      mdct_long_r4(in0, S.u.m.zz.z, coef, G4, T, RT);
       __syncthreads();
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
@@ -671,31 +768,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
           if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
         }
         __syncthreads();
-        float2 *z = S.u.m.zz.z;
-        if (!(L.debug & 32)) {
-        mdct_pre(in0, T->mdct_fwd256, 2 * lane, g256a, z);
-        mdct_pre(in1, T->mdct_fwd256, 2 * lane, g256b, z);
-        mdct_pre(in2, T->mdct_fwd512, 2 * lane, g512a, z + 128);
-        mdct_pre(in2, T->mdct_fwd512, 2 * lane + 128, g512b, z + 128);
-        }
-        __syncthreads();
-        // FFT: two 64-point transforms in z[0,128), one 128-point transform in z[128,256)
-        if (!(L.debug & 8)) {
-        fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
-        fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
-        fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
-        fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
-        fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
-        fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
-        fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
-        }
         float *coef = S.u.m.a.c.coef;
-        if (!(L.debug & 32)) {
-        mdct_post<64, false>(z, ps0, T->mdct_fwd256, lane, coef);
-        mdct_post<64, true>(z, ps1, T->mdct_fwd256, lane, coef + 128);
-        mdct_post<128, true>(z + 128, ps0, T->mdct_fwd512, lane, coef + 256);
-        mdct_post<128, true>(z + 128, ps1, T->mdct_fwd512, lane + 64, coef + 256);
-        }
+        mdct_long_r4(in0, S.u.m.zz.z, coef, G4, T, RT);
         __syncthreads();
 
         // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------

@@ -11,7 +11,7 @@ def short(name):
 
 
 for d in sys.argv[1:]:
-    for f in glob.glob(d + '/*/*_counter_collection.csv'):
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         rows = list(csv.DictReader(open(f)))
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         disp = collections.defaultdict(set)
