@@ -247,8 +247,12 @@ struct alignas(16) LongLds {
         struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // MDCT inputs
         struct { alignas(16) float coef[512]; } c;                                                           // coefficients (after the pre-twiddle)
       } a;
-      union alignas(16) { float2 z[320]; float band[512]; } zz;   // FFT points (4 pad per 16); before the pre-twiddle: low128 | mid128 | high256, raw
+      union alignas(16) { float band[512]; } zz;   // before the pre-twiddle: low128 | mid128 | high256, raw
     } m;
+    // FFT points (4 pad slots per 16).  They start 512 bytes before the end of the MDCT inputs: round A has read
+    // every input before it writes its first point (one wave, LDS operations in issue order), and the overlap
+    // keeps a wave at 8 128 bytes, i.e. 20 waves per CU
+    struct { alignas(16) float skip_[896]; float2 z[320]; } zp;
   } u;
 };
 
@@ -401,6 +405,22 @@ __device__ __forceinline__ void r2_butterfly(float2 &e, float2 &o, const double2
   o = make_float2(f32(er - xr), f32(ei - xi));
 }
 
+// The same butterfly when the twiddle is exactly (1, 0) (k = 0 of every stage, fft.js:44-45).  Then
+// xr = or*1 - oi*0 == or and xi = or*0 + oi*1 == oi whenever or, oi are finite and not -0 (only then can the
+// signed-zero products change the sum), and Float32(er + or) computed in binary64 equals the binary32 sum
+// (53 >= 2*24 + 2: the double rounding is innocuous).  r2_unit_ok is that precondition; callers take the
+// general butterfly when any lane fails it, so the result is the reference's in every case.
+__device__ __forceinline__ bool r2_unit_ok(const float2 e, const float2 o) {
+  constexpr int kFinite = 0x1F8, kFiniteNotNegZero = 0x1D8;   // v_cmp_class masks
+  return __builtin_amdgcn_classf(e.x, kFinite) && __builtin_amdgcn_classf(e.y, kFinite) &&
+         __builtin_amdgcn_classf(o.x, kFiniteNotNegZero) && __builtin_amdgcn_classf(o.y, kFiniteNotNegZero);
+}
+__device__ __forceinline__ void r2_butterfly_unit(float2 &e, float2 &o) {
+  const float2 a = e, b = o;
+  e = make_float2(a.x + b.x, a.y + b.y);
+  o = make_float2(a.x - b.x, a.y - b.y);
+}
+
 // in: 1024 floats (in0 | in1 | in2, zero padded long-block inputs); z: 320 slots; coef: 512 floats (may share
 // memory with `in`: the inputs are dead once round A has read them)
 __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R) {
@@ -426,8 +446,12 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
     const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]);
     const double2 w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
     const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]);
-    r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0);
-    r2_butterfly(x[0], x[2], w1); r2_butterfly(x[1], x[3], w2);
+    // stages 1 and 2: three of the four butterflies have the twiddle (1, 0) -> Float32 adds when that is exact
+    if (__all(r2_unit_ok(x[0], x[1]) && r2_unit_ok(x[2], x[3]))) { r2_butterfly_unit(x[0], x[1]); r2_butterfly_unit(x[2], x[3]); }
+    else { r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0); }
+    if (__all(r2_unit_ok(x[0], x[2]))) r2_butterfly_unit(x[0], x[2]);
+    else r2_butterfly(x[0], x[2], w1);
+    r2_butterfly(x[1], x[3], w2);
     float4 *dst = reinterpret_cast<float4 *>(z + G.za);
     dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
     dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
@@ -471,7 +495,7 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
 }
 
 template <bool DETECT, bool ALL_LONG>
-__global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_analysis_fast(C1EncodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 3 : (DETECT ? 2 : 3)) void k_analysis_fast(C1EncodeLaunch L) {
   static_assert(!(DETECT && ALL_LONG), "detection decides the modes per frame");
   using Lds = typename std::conditional<ALL_LONG, LongLds, MixedLds>::type;
   __shared__ Lds S;
@@ -605,7 +629,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : (DETECT ? 2 : 3)) void k_an
       }
       __syncthreads();
       float *coef = S.u.m.a.c.coef;
-      mdct_long_r4(in0, S.u.m.zz.z, coef, G4, T, RT);
+      mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT);
       __syncthreads();
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
@@ -1895,3 +1919,4 @@ void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, fl
   const int64_t segs = (frames + 511) / 512;
   hipLaunchKernelGGL(k_generate_pink, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, stream, segment_states, frames, pcm);
 }
+static_assert(sizeof(LongLds) <= 8192, "all-long analysis: 20 waves per CU need <= 8 KiB of LDS per wave");

@@ -347,3 +347,24 @@ def test_wav16_file_to_aea_to_wav16_device_chain(ctx):
     p, _ = O.decode_stream(u, 2)
     assert np.array_equal(units.cpu().numpy().reshape(-1, 212), u)
     assert np.array_equal(out.cpu().numpy(), O.pcm_to_int16(p))
+
+
+def test_signed_zero_and_non_finite_pcm_take_the_reference_arithmetic(ctx):
+    """The kernels use binary32 shortcuts for unit twiddles only when that is exact; -0, infinities and NaN in the
+    PCM must fall back to the reference's binary64 expressions.  Units against the oracle, fixed and detected modes."""
+    import carta1_amd as c1
+    n = 48 * 512
+    rng = np.random.default_rng(77)
+    pcm = O.gen_white(31, n).copy()
+    pcm[rng.integers(0, n, 4000)] = -0.0
+    pcm[5 * 512:7 * 512] = 0.0                       # two silent frames: zeros of both signs inside the transforms
+    pcm[6 * 512 + 17] = -0.0
+    pcm[20 * 512 + 3] = np.inf
+    pcm[21 * 512 + 100] = -np.inf
+    pcm[30 * 512 + 7] = np.nan
+    pcm[40 * 512:41 * 512] *= 1e-38                  # denormal range
+    for opts in ({'fixedBlockModes': [0, 0, 0]}, {}, {'fixedBlockModes': [2, 2, 3]}):
+        want, _ = O.encode_stream([pcm], fixed_modes=opts.get('fixedBlockModes'))
+        got = ctx.encode([pcm], c1.EncoderOptions(opts))
+        bad = first_diff(got, want)
+        assert len(bad) == 0, (opts, bad)
