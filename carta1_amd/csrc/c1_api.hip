@@ -213,6 +213,11 @@ struct c1_ctx {
   uint8_t *d_alloc[2] = {nullptr, nullptr};
   uint8_t *d_cand[2] = {nullptr, nullptr};
   uint32_t *d_work[2] = {nullptr, nullptr};      // [0] = count, list from [4]
+  // transient-detection workspace (allocated on first use): band samples, feature sums, block modes
+  int64_t det_units = 0;
+  float *d_bands[2] = {nullptr, nullptr};
+  double *d_feat[2] = {nullptr, nullptr};
+  uint8_t *d_modes[2] = {nullptr, nullptr};
   int64_t chunk_frames = 0;
   bool pipeline = true;
   hipStream_t s_ana = nullptr, s_rest = nullptr;  // internal streams of the two pipeline halves
@@ -246,6 +251,30 @@ void free_workspace(c1_ctx *ctx) {
     ctx->d_coefs[p] = nullptr; ctx->d_side[p] = nullptr; ctx->d_alloc[p] = nullptr; ctx->d_cand[p] = nullptr; ctx->d_work[p] = nullptr;
   }
   ctx->ws_units = 0;
+  for (int p = 0; p < 2; p++) {
+    if (ctx->d_bands[p]) (void)hipFree(ctx->d_bands[p]);
+    if (ctx->d_feat[p]) (void)hipFree(ctx->d_feat[p]);
+    if (ctx->d_modes[p]) (void)hipFree(ctx->d_modes[p]);
+    ctx->d_bands[p] = nullptr; ctx->d_feat[p] = nullptr; ctx->d_modes[p] = nullptr;
+  }
+  ctx->det_units = 0;
+}
+
+int ensure_detect_workspace(c1_ctx *ctx, int64_t units) {
+  if (units <= ctx->det_units) return C1_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  for (int p = 0; p < (ctx->pipeline ? 2 : 1); p++) {
+    if (ctx->d_bands[p]) (void)hipFree(ctx->d_bands[p]);
+    if (ctx->d_feat[p]) (void)hipFree(ctx->d_feat[p]);
+    if (ctx->d_modes[p]) (void)hipFree(ctx->d_modes[p]);
+    ctx->d_bands[p] = nullptr; ctx->d_feat[p] = nullptr; ctx->d_modes[p] = nullptr;
+    // one extra row of slots in front: frame -1 of the batch (c1_internal.h)
+    HIP_TRY(hipMalloc(&ctx->d_bands[p], (size_t)(units + C1_MAX_CHANNELS) * 512 * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_feat[p], (size_t)(units + C1_MAX_CHANNELS) * kFeatureWsDoubles * sizeof(double)));
+    HIP_TRY(hipMalloc(&ctx->d_modes[p], (size_t)units));
+  }
+  ctx->det_units = units;
+  return C1_OK;
 }
 
 int ensure_workspace(c1_ctx *ctx, int64_t units) {
@@ -359,6 +388,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   const int64_t chunk = ctx->chunk_frames;
   const bool taps = coefs_tap || side_tap || alloc_tap;
   if ((rc = ensure_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
+  if (detect && (rc = ensure_detect_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (taps && (!coefs_tap || !side_tap || !alloc_tap)) return fail(C1_ERR_ARG, "coefs, side and alloc taps must be given together");
   // Two-stage software pipeline over chunks: the analysis of chunk i+1 (fp64-VALU bound) runs on one
   // stream while allocation + packing of chunk i (latency bound) run on another, each chunk on its own
@@ -397,7 +427,11 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     {
       ScopedTiming t(ctx, K_ANALYSIS, sA);
       if (all_long) c1k_launch_analysis_long(L, sA);
-      else c1k_launch_analysis(L, detect, sA);
+      else if (detect) {
+        c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], sA);
+        if (L.bands) HIP_TRY(hipMemcpyAsync(L.bands, ctx->d_bands[p] + (size_t)channels * 512, (size_t)n * channels * 512 * sizeof(float),
+                                            hipMemcpyDeviceToDevice, sA));
+      } else c1k_launch_analysis(L, false, sA);
     }
     if (piped) {
       HIP_TRY(hipEventRecord(ctx->ev_ana[p], sA));

@@ -80,6 +80,10 @@ struct C1DecodeLaunch {
 // launchers (c1_kernels.hip); all asynchronous on `stream`
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0]
+// transient detection: features (runs) -> decisions (per unit) -> MDCT from the stored bands (per unit).
+// bands_ws: (units + channels) * 512 floats, feat_ws: (units + channels) * kFeatureWsDoubles doubles, modes_ws: units bytes
+constexpr int kFeatureWsDoubles = 20;
+void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
