@@ -225,11 +225,9 @@ struct FrameModes {
 // =====================================================================================================
 // k_analysis_fast : QMF -> block selection -> MDCT -> scale factors, one wave per run of frames
 // =====================================================================================================
-// template <DETECT, ALL_LONG>:
-//   <false,true>   fixed block modes [0,0,0]: the long-block MDCT core below and nothing else
-//   <false,false>  any other fixed modes: frames go through the generic (mode-aware) MDCT staging
-//   <true,false>   transient detection: per frame the three block modes are decided, then all-long frames
-//                  (the common case) take the long-block core and the rest the generic staging
+// Fixed block modes only (transient detection has its own pipeline further down).  template <ALL_LONG>:
+//   <true>    modes [0,0,0]: the long-block MDCT core and nothing else
+//   <false>   any other fixed modes: staging + the mixed long/short core
 // Every vector instruction costs the same 4 cycles here, so the long-block core is shaped to minimise
 // their count: MDCT inputs in LDS buffers, FFT on interleaved (re,im) pairs with lane-only geometry
 // computed once per wave, bank-conflict-free layouts (tools/lds_model.py), no per-element mode logic.
@@ -262,25 +260,17 @@ struct alignas(16) MixedLds {
   alignas(16) float band[512];
   alignas(16) float hbuf[296];
   alignas(4) uint8_t sfi[64];
-  float ovl[96];                 // mdctOverlap, 3 x 32 (the all-long kernel keeps it in registers)
-  float mag[2][256];             // transientDetection magnitudes, current / previous (ping-pong)
-  double sums[18];
+  alignas(16) float ovl[96];     // mdctOverlap, 3 x 32 (the all-long kernel keeps it in registers)
   union alignas(16) {
     struct { alignas(16) double w1[698]; } q1;
     struct { alignas(16) double w2[454]; } q2;
     struct {
       union alignas(16) {
-        struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // long-block inputs
-        struct { alignas(16) float in[1024]; } g;                                                            // generic staging
+        struct { alignas(16) float in[1120]; } g;      // staging (kStageFloats)
         struct { alignas(16) float coef[512]; } c;
       } a;
-      union alignas(16) {
-        float2 z[320];
-        struct { float re[256]; float im[256]; } ri;
-      } zz;
+      union alignas(16) { float2 z[320]; } zz;
     } m;
-    struct { float re[512]; float im[512]; } t;      // transient FFT: 128 | 128 | 256 points
-    struct { double term[4][256]; } tt;              // per-bin feature terms (after the magnitudes are taken)
   } u;
 };
 
@@ -314,82 +304,6 @@ __device__ __forceinline__ void fft_butterfly(float2 *z, int pe, int po, int tw,
   const double xi = orr * ti + oi * tr;
   z[pe] = make_float2(f32(er + xr), f32(ei + xi));
   z[po] = make_float2(f32(er - xr), f32(ei - xi));
-}
-
-// ---- MDCT of one frame for any block modes (mdctStage, encoder.js:170-349) --------------------------------------
-// band: low128 | mid128 | high256 raw samples; ovl: 3 x 32 windowed tails of the previous frame; in: 1024 floats of
-// staging; re/im: 256 points; coef: 512 outputs (may share memory with `in`).  Ends with the coefficients visible.
-__device__ __forceinline__ void mdct_any_modes(const float *band_, const float *ovl_, float *in, float *re, float *im,
-                                               float *coef, const FrameModes &M, int lane, TablesPtr T) {
-    // MDCT inputs of the three bands (long: zero | overlap | samples with windowed tail | zero,
-    // encoder.js:228-258; short: [overlap | windowed block] per 32-sample block, :269-307)
-#pragma unroll
-    for (int m = 0; m < 16; m++) {
-      const int g = lane + 64 * m;
-      const int b = g < 256 ? 0 : (g < 512 ? 1 : 2);
-      const int l = g - (b == 0 ? 0 : (b == 1 ? 256 : 512));
-      const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-      float v = 0.0f;
-      if (M.mode_of_band(b) == 0) {
-        const int ws = b == 2 ? 112 : 48;
-        const int x = l - ws - 32;
-        if (l >= ws && l < ws + 32) v = ovl_[32 * b + (l - ws)];
-        else if (x >= 0 && x < Sb - 32) v = band_[off + x];
-        else if (x >= Sb - 32 && x < Sb) v = f32((double)band_[off + x] * T->window[31 - (x - (Sb - 32))]);
-      } else {
-        const int q = l >> 6, pos = l & 63;
-        if (pos < 32) v = q == 0 ? ovl_[32 * b + pos] : f32(T->window[pos] * (double)band_[off + 32 * (q - 1) + pos]);
-        else v = f32((double)band_[off + 32 * q + (pos - 32)] * T->window[31 - (pos - 32)]);
-      }
-      in[g] = v;
-    }
-  __syncthreads();
-    // pre-twiddle (mdct.js:76-105) straight into bit-reversed order
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int p = lane + 64 * m;
-      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
-      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), ibase = b == 0 ? 0 : (b == 1 ? 256 : 512);
-      const bool lng = M.mode_of_band(b) == 0;
-      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
-      const int lg = lng ? (b == 2 ? 7 : 6) : 4;
-      const int q = lng ? 0 : ((p - cbase) >> 4);
-      const int k = (p - cbase) - q * nfft;
-      const float *x = in + ibase + q * 64;
-      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
-      const int n4 = nfft, n34 = 3 * nfft, i = 2 * k;
-      double r, mm;
-      if (i < n4) { r = (double)x[n34 - 1 - i] + (double)x[n34 + i]; mm = (double)x[n4 + i] - (double)x[n4 - 1 - i]; }
-      else { r = (double)x[n34 - 1 - i] - (double)x[i - n4]; mm = (double)x[n4 + i] + (double)x[5 * n4 - 1 - i]; }
-      const double c = tab[i], s = tab[i + 1];
-      const int dst = cbase + q * nfft + bitrev(k, lg);
-      re[dst] = f32(r * c + mm * s);
-      im[dst] = f32(mm * c - r * s);
-    }
-    __syncthreads();
-    fft_stages<256>(re, im, lane, T, 128, [&](int e) { return M.fft_size_at(e); });
-    // post-twiddle (mdct.js:110-119) + spectrum reversal of bands 1,2 (utils.js:42-48)
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int p = lane + 64 * m;
-      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
-      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
-      const bool lng = M.mode_of_band(b) == 0;
-      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
-      const int q = lng ? 0 : ((p - cbase) >> 4);
-      const int i = (p - cbase) - q * nfft;
-      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_fwd512 : T->mdct_fwd256) : T->mdct_fwd64;
-      const int n2 = 2 * nfft;
-      const double c = tab[2 * i], s = tab[2 * i + 1], rr = re[p], ii = im[p];
-      const float o0 = f32(-rr * c - ii * s);
-      const float o1 = f32(-rr * s + ii * c);
-      const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
-      float *dst = coef + obase + q * 32;
-      if (b > 0) { dst[n2 - 1 - j0] = o0; dst[n2 - 1 - j1] = o1; }
-      else { dst[j0] = o0; dst[j1] = o1; }
-    }
-    __syncthreads();
-
 }
 
 // ---- long-block MDCT core, radix-4 rounds -------------------------------------------------------------
@@ -570,9 +484,181 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
   }
 }
 
-template <bool DETECT, bool ALL_LONG>
-__global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 3 : (DETECT ? 2 : 3)) void k_analysis_fast(C1EncodeLaunch L) {
-  static_assert(!(DETECT && ALL_LONG), "detection decides the modes per frame");
+
+// ---- MDCT core for frames with short blocks, radix-4 rounds ------------------------------------------------------
+// Same lane ownership as mdct_long_r4 (lanes 0..15 band 0, 16..31 band 1, 32..63 band 2, four points per lane).
+// A short band is 4 (8 for band 2) blocks of 32 samples, each a 64-sample MDCT = a 16-point transform = exactly
+// rounds A and B; a long band of the same frame goes on through rounds C (and D).  Inputs come from a staging
+// buffer of three regions R_b (floats 0, 288, 576):
+//   long band   zero | overlap | samples, last 32 windowed | zero            (encoder.js:228-258)
+//   short band  E = overlap(32) | W[s & 31] * x[s]      then   H = x[s] * W[31 - (s & 31)]
+//               so that block q reads its first half at E[32q + i] and its second at H[32q + i]  (encoder.js:269-307)
+constexpr int kStageFloats = 1120;
+__device__ __forceinline__ int stage_region(int band) { return band == 0 ? 0 : (band == 1 ? 288 : 576); }
+
+struct MixGeometry {
+  int ia[4], ib[4], ic[4], id[4];
+  int pre_tab[4];
+  int za, zb, zc, zd, twb, twc, twd;
+  int post_tab[4], cx[4], cy[4];
+  bool is_long, band2;
+};
+
+__device__ __forceinline__ MixGeometry mix_geometry(int lane, const FrameModes &M) {
+  MixGeometry G;
+  const int band = lane < 16 ? 0 : (lane < 32 ? 1 : 2);
+  const int g = lane - (band == 0 ? 0 : (band == 1 ? 16 : 32));
+  const bool lng = M.mode_of_band(band) == 0;
+  const int R = stage_region(band), Sb = band == 2 ? 256 : 128;
+  const int n4 = lng ? (band == 2 ? 128 : 64) : 16, q4 = n4 / 4;
+  const int r = lng ? bitrev(g, band == 2 ? 5 : 4) : bitrev(g & 3, 2);
+  const int blk = g >> 2;                                  // short: block of the band
+  const int tab_base = lng ? (band == 2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256))
+                           : (int)offsetof(C1DevTables, mdct_fwd64);
+  const int tw_base = (int)offsetof(C1DevTables, fft_tw);
+  // operand idx of a 4*n4-sample input -> float index in the staging buffer
+  auto at = [&](int idx) { return lng ? R + idx : (idx < 32 ? R + 32 * blk + idx : R + 32 + Sb + 32 * blk + (idx - 32)); };
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int jp = ((j & 1) << 1) | (j >> 1);
+    const int k = r + q4 * jp, i = 2 * k;
+    const bool hi = (j & 1) != 0;                          // k >= n4/2 for positions 4g+1 and 4g+3
+    G.ia[j] = at(3 * n4 - 1 - i);
+    G.ic[j] = at(n4 + i);
+    G.ib[j] = at(hi ? i - n4 : 3 * n4 + i);
+    G.id[j] = at(hi ? 5 * n4 - 1 - i : n4 - 1 - i);
+    G.pre_tab[j] = tab_base + 16 * k;
+  }
+  const int pbase = band == 0 ? 0 : (band == 1 ? 64 : 128);
+  G.za = zslot(pbase + 4 * g);
+  G.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
+  G.twb = tw_base + 16 * (3 + (g & 3));
+  G.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
+  G.twc = tw_base + 16 * (15 + (g & 15));
+  G.zd = zslot(128 + (g & 31));
+  G.twd = tw_base + 16 * (63 + (g & 31));
+  G.is_long = lng;
+  G.band2 = band == 2;
+  const int cbase = band == 0 ? 0 : (band == 1 ? 128 : 256);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int i, e0, e1;
+    if (lng) {
+      i = band == 2 ? g + (j == 1 ? 64 : (j == 2 ? 32 : (j == 3 ? 96 : 0))) : g + 16 * j;
+      e0 = cbase + 2 * i; e1 = cbase + 2 * n4 - 1 - 2 * i;
+    } else {
+      i = (g & 3) + 4 * j;                                 // points of block blk after round B
+      e0 = cbase + 32 * blk + 2 * i; e1 = cbase + 32 * blk + 31 - 2 * i;
+    }
+    G.post_tab[j] = tab_base + 16 * i;
+    G.cx[j] = band == 0 ? e0 : e1;
+    G.cy[j] = band == 0 ? e1 : e0;
+  }
+  return G;
+}
+
+// staging buffer of one frame from its raw bands and the previous frame's windowed tails (ovl: 3 x 32)
+__device__ __forceinline__ void mix_stage(const float *band_, const float *ovl_, float *stage, const FrameModes &M, int lane,
+                                          TablesRsrc RT) {
+  // window values of the lane's four samples (same residue mod 32 in both passes): W[4(l&7)+d] and W[31-4(l&7)-d]
+  const int wofs = (int)offsetof(C1DevTables, window) + 8 * 4 * (lane & 7);
+  const double2 wl01 = table_pair(RT, wofs), wl23 = table_pair(RT, wofs + 16);
+  const int hofs = (int)offsetof(C1DevTables, window) + 8 * (28 - 4 * (lane & 7));
+  const double2 wh32 = table_pair(RT, hofs), wh10 = table_pair(RT, hofs + 16);    // W[28-4m .. 31-4m]
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int b = pass == 0 ? (lane >> 5) : 2;
+    const int s = pass == 0 ? 4 * (lane & 31) : 4 * lane;
+    const int Sb = b == 2 ? 256 : 128, R = stage_region(b), ws = b == 2 ? 112 : 48;
+    const bool lng = M.mode_of_band(b) == 0;
+    const float4 v = *reinterpret_cast<const float4 *>(band_ + (b == 0 ? 0 : (b == 1 ? 128 : 256)) + s);
+    float4 lo, hi;
+    lo.x = f32(wl01.x * (double)v.x); lo.y = f32(wl01.y * (double)v.y); lo.z = f32(wl23.x * (double)v.z); lo.w = f32(wl23.y * (double)v.w);
+    hi.x = f32((double)v.x * wh10.y); hi.y = f32((double)v.y * wh10.x); hi.z = f32((double)v.z * wh32.y); hi.w = f32((double)v.w * wh32.x);
+    if (lng) {
+      *reinterpret_cast<float4 *>(stage + R + ws + 32 + s) = (s >= Sb - 32) ? hi : v;
+    } else {
+      *reinterpret_cast<float4 *>(stage + R + 32 + s) = lo;
+      *reinterpret_cast<float4 *>(stage + R + 32 + Sb + s) = hi;
+    }
+    // overlap of the previous frame, and the zero regions of a long band
+    const int l8 = pass == 0 ? (lane & 31) : lane;
+    if (l8 < 8) *reinterpret_cast<float4 *>(stage + R + (lng ? ws : 0) + 4 * l8) = *reinterpret_cast<const float4 *>(ovl_ + 32 * b + 4 * l8);
+    if (lng) {
+      const int nz = ws / 4;                                 // float4 per zero region: [0, ws) and [ws + 32 + Sb, 2 ws + 32 + Sb)
+      const int l = l8 - 8;
+      if (l >= 0 && l < 2 * nz) *reinterpret_cast<float4 *>(stage + R + (l < nz ? 4 * l : ws + 32 + Sb + 4 * (l - nz))) = zero4;
+    }
+  }
+}
+
+// stage: staging buffer; z: 320 slots; coef: 512 floats (may share memory with `stage`).  any_long / band2_long are
+// wave-uniform.  Ends without a fence after the coefficient writes.
+__device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, float *coef, const MixGeometry &G, bool any_long,
+                                              bool band2_long, TablesPtr T, TablesRsrc R) {
+  float2 x[4];
+  {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double a = stage[G.ia[j]], b = stage[G.ib[j]], c = stage[G.ic[j]], d = stage[G.id[j]];
+      const double2 t = table_pair(R, G.pre_tab[j]);
+      const double r = (j & 1) ? a - b : a + b;             // mdct.js:84-99
+      const double m = (j & 1) ? c + d : c - d;
+      x[j] = make_float2(f32(r * t.x + m * t.y), f32(m * t.x - r * t.y));
+    }
+    const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]);
+    const double2 w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
+    const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]);
+    if (__all(r2_unit_ok(x[0], x[1]) && r2_unit_ok(x[2], x[3]))) { r2_butterfly_unit(x[0], x[1]); r2_butterfly_unit(x[2], x[3]); }
+    else { r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0); }
+    if (__all(r2_unit_ok(x[0], x[2]))) r2_butterfly_unit(x[0], x[2]);
+    else r2_butterfly(x[0], x[2], w1);
+    r2_butterfly(x[1], x[3], w2);
+    float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+    dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+    dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+  }
+  __syncthreads();
+  {
+    float2 *p = z + G.zb;
+    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
+    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+    r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+    if (G.is_long) { p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3]; }
+  }
+  if (any_long) {
+    __syncthreads();
+    if (G.is_long) {
+      float2 *p = z + G.zc;
+      const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
+      x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
+      r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+      r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+      if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
+    }
+    if (band2_long) {
+      __syncthreads();
+      if (G.band2) {
+        const float2 *p = z + G.zd;
+        const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);
+        x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
+        r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wb);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double2 t = table_pair(R, G.post_tab[j]);
+    const double rr = x[j].x, ii = x[j].y;
+    coef[G.cx[j]] = f32(-rr * t.x - ii * t.y);
+    coef[G.cy[j]] = f32(-rr * t.y + ii * t.x);
+  }
+}
+
+template <bool ALL_LONG>
+__global__ __launch_bounds__(C1_WAVE, 3) void k_analysis_fast(C1EncodeLaunch L) {
   using Lds = typename std::conditional<ALL_LONG, LongLds, MixedLds>::type;
   __shared__ Lds S;
   float *band_;                                        // low128 | mid128 | high256 of the current frame, raw
@@ -589,18 +675,16 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 3 : (DETECT ? 2 : 3)) void k_an
   if (lane < 12) S.sfi[52 + lane] = 0;   // modes byte (all long) and padding of the side record
   if constexpr (!ALL_LONG) {
     for (int i = lane; i < 96; i += 64) S.ovl[i] = 0.0f;
-    for (int i = lane; i < 512; i += 64) (&S.mag[0][0])[i] = 0.0f;
   }
-  int cur = 0;                                           // which half of S.mag is "current"
-  double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;   // lane b < 3: features of the previous frame, band b
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   // lane-only geometry of the long-block MDCT core, computed once (everything else is re-derived per frame)
   const R4Geometry G4 = r4_geometry(lane0);
+  const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
-  constexpr int kWarm = DETECT ? 2 : 1;            // frames of history that rebuild the state
+  constexpr int kWarm = 1;                         // one frame of history rebuilds the state
   int64_t f_first = f0 - kWarm;
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;   // before the stream start the zero state stays
   if (f_first > f0) f_first = f0;
@@ -612,7 +696,6 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 3 : (DETECT ? 2 : 3)) void k_an
   }
   for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = (f >= f0);
-    const bool qmf_only = DETECT && (f == f0 - 2);   // detect warm-up frame -2 only feeds the delay lines
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
 
@@ -662,7 +745,6 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 3 : (DETECT ? 2 : 3)) void k_an
       __syncthreads();
       if (lane < 39) S.hbuf[lane] = keep;
     }
-    if (qmf_only) { __syncthreads(); continue; }
     if (emit && L.bands) {
       float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
       const float4 *src = reinterpret_cast<const float4 *>(band_);
@@ -736,208 +818,46 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 3 : (DETECT ? 2 : 3)) void k_an
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
       __syncthreads();
     } else {
-      // ---------------- blockSelectorStage (encoder.js:111-152) ----------------
-      FrameModes M{O->modes[0], O->modes[1], O->modes[2]};
-      if (DETECT) {
-        float *re = S.u.t.re, *im = S.u.t.im;
-        float *mcur = S.mag[cur];
-        const float *mprev = S.mag[cur ^ 1];
-        // performFFT (transient.js:17-35): real input, three transforms 128 | 128 | 256 in one buffer
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const int p = lane + 64 * m;
-          const int base = p < 128 ? 0 : (p < 256 ? 128 : 256);
-          const int lg = p < 256 ? 7 : 8;
-          re[base + bitrev(p - base, lg)] = band_[p];
-          im[p] = 0.0f;
-        }
+      // ---------------- mdctStage with short blocks (encoder.js:170-349), fixed block modes ----------------
+      const FrameModes M{O->modes[0], O->modes[1], O->modes[2]};
+      float *coef = S.u.m.a.c.coef;
+      if (emit) {
+        mix_stage(band_, S.ovl, S.u.m.a.g.in, M, lane, RT);
         __syncthreads();
-        fft_stages<512>(re, im, lane, T, 256, [](int e) { return e < 256 ? 128 : 256; });
-        // magnitudes of the positive-frequency half (transient.js:29-32) + per-bin terms of the features
-        bool valid[4];
-        float mgs[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const int g = lane + 64 * m;                        // mag index: band0 [0,64) band1 [64,128) band2 [128,256)
-          const int src = g < 64 ? g : (g < 128 ? 128 + (g - 64) : 256 + (g - 128));
-          const double r = re[src], i = im[src];
-          mgs[m] = f32(sqrt(r * r + i * i));
-        }
-        __syncthreads();                                      // the per-bin terms reuse the memory of re/im
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const int g = lane + 64 * m;
-          const float mg = mgs[m];
-          mcur[g] = mg;
-          const double cm = (double)mg, pm = (double)mprev[g];
-          const double diff = cm - pm;
-          valid[m] = cm > 1e-10;
-          S.u.tt.term[0][g] = diff > 0 ? diff : 0.0;          // spectral flux terms (transient.js:96-106)
-          S.u.tt.term[1][g] = cm * cm;                        // energy terms (exact product)
-          S.u.tt.term[2][g] = valid[m] ? log(cm) : 0.0;       // flatness terms (transient.js:126-133)
-          S.u.tt.term[3][g] = valid[m] ? cm : 0.0;
-        }
-        const int nv0 = __popcll(__ballot(valid[0])), nv1 = __popcll(__ballot(valid[1]));
-        const int nv2 = __popcll(__ballot(valid[2])) + __popcll(__ballot(valid[3]));
-        __syncthreads();
-        // the reference accumulates every feature sequentially in double, index ascending; keep that
-        // order: 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high})
-        if (lane < 18) {
-          const int b = lane / 6, kind = lane - 6 * b;
-          const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
-          const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
-          const int start = g0 + (kind == 5 ? n / 2 : 0);
-          const int len = kind >= 4 ? n / 2 : n;
-          const double *arr = S.u.tt.term[which] + start;
-          double acc = 0.0;
-          for (int i = 0; i < len; i++) acc += arr[i];
-          S.sums[lane] = acc;
-        }
-        __syncthreads();
-        int mode = 0;
-        if (lane < 3) {
-          const double s_flux = S.sums[6 * lane + 0], s_e = S.sums[6 * lane + 1], s_log = S.sums[6 * lane + 2];
-          const double s_lin = S.sums[6 * lane + 3], s_lo = S.sums[6 * lane + 4], s_hi = S.sums[6 * lane + 5];
-          const int nv = lane == 0 ? nv0 : (lane == 1 ? nv1 : nv2);
-          double norm = sqrt(s_e);
-          if (!(norm != 0.0)) norm = 1e-6;                     // `Math.sqrt(e) || 1e-6`
-          const double flux = s_flux / norm;
-          double flat = 0.0;                                    // calculateSpectralFlatness :120-141
-          if (nv > 0) {
-            const double gm = exp(s_log / (double)nv), am = s_lin / (double)nv;
-            flat = am > 1e-10 ? gm / am : 0.0;
-          }
-          const double tot = s_lo + s_hi;                       // calculateHighFrequencyRatio :149-164
-          const double hf = tot > 0 ? s_hi / tot : 0.0;
-          const double ce = s_e > 1e-10 ? s_e : 1e-10;          // calculateEnergyChange :172-189
-          const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
-          const double db = 10.0 * log10(ce / pe);
-          const double e_change = db > 0 ? db : 0.0;
-          const double flat_c = sqrt(fabs(flat - prev_flat));   // calculateTransientScore :197-226
-          const double hf_c = log1p(fabs(hf - prev_hf) * 10.0) / T->log1p10;
-          const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
-          const double score = (flux + flat_c + hf_c + e_c) / 4.0;
-          mode = (score > O->threshold) ? (lane + 1 > 2 ? lane + 1 : 2) : 0;   // encoder.js:143
-          prev_flat = flat; prev_hf = hf; prev_e = s_e;
-        }
-        M.m0 = __shfl(mode, 0); M.m1 = __shfl(mode, 1); M.m2 = __shfl(mode, 2);
-        cur ^= 1;
-        __syncthreads();
+        mdct_mixed_r4(S.u.m.a.g.in, S.u.m.zz.z, coef, GM, M.m0 == 0 || M.m1 == 0 || M.m2 == 0, M.m2 == 0, T, RT);
       }
-
-      if (!emit) {
-        // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
-        for (int i = lane; i < 96; i += 64) {
-          const int b = i >> 5, k = i & 31;
-          const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-          S.ovl[i] = f32(T->window[k] * (double)band_[off + Sb - 32 + k]);
-        }
-        __syncthreads();
-        continue;
+      // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
+      for (int i = lane; i < 96; i += 64) {
+        const int b = i >> 5, k = i & 31;
+        const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+        S.ovl[i] = f32(T->window[k] * (double)band_[off + Sb - 32 + k]);
       }
-      if (M.m0 == 0 && M.m1 == 0 && M.m2 == 0) {
-        // ---------------- mdctStage, long blocks (encoder.js:228-258, 309-316) ----------------
-        // tail of every band: windowed copy into this frame's MDCT input, overlap for the next frame
-        float *in0 = S.u.m.a.i.in0, *in1 = S.u.m.a.i.in1, *in2 = S.u.m.a.i.in2;
-        float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
-        if (lane < 32) {
-          const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
-          const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
-          nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
-          if (emit) {
-            in0[48 + lane] = S.ovl[lane]; in1[48 + lane] = S.ovl[32 + lane]; in2[112 + lane] = S.ovl[64 + lane];
-            in0[80 + 96 + lane] = f32(x0 * w_hi);
-            in1[80 + 96 + lane] = f32(x1 * w_hi);
-            in2[144 + 224 + lane] = f32(x2 * w_hi);
-          }
-        }
-        if (lane < 32) { S.ovl[lane] = nov0; S.ovl[32 + lane] = nov1; S.ovl[64 + lane] = nov2; }
-        // zero regions and the body of every band (everything before the tail) straight into the MDCT inputs
-        {
-          const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (lane < 48) {
-            float *inb = lane < 24 ? in0 : in1;
-            const int q = lane < 24 ? lane : lane - 24;                 // 24 float4 per band: [0,48) and [208,256)
-            *reinterpret_cast<float4 *>(&inb[q < 12 ? 4 * q : 208 + 4 * (q - 12)]) = zero4;
-          }
-          if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
-          if (lane < 48) {
-            *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[2 * lane]);
-            *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[128 + 2 * lane]);
-          }
-          if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
-        }
-        __syncthreads();
-        float *coef = S.u.m.a.c.coef;
-        mdct_long_r4(in0, S.u.m.zz.z, coef, G4, T, RT);
-        __syncthreads();
+      __syncthreads();
+      if (!emit) continue;
 
-        // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
-        const int64_t unit = f * L.channels + ch;
-        {
-          float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
-          const float4 *src = reinterpret_cast<const float4 *>(coef);
-          dst[lane] = src[lane];
-          dst[64 + lane] = src[64 + lane];
-        }
-        {
-          // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
-          // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
-          const bool wide = lane >= 44;
-          const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
-          const int half = wide ? (lane & 1) : 0;
-          const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
-          const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
-          float mx = 0.0f;
-#pragma unroll
-          for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
-          mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
-          const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
-          if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
-          if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
-        }
-        __syncthreads();
-        if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-        __syncthreads();
+      // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+      const int64_t unit = f * L.channels + ch;
+      {
+        float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+        const float4 *src = reinterpret_cast<const float4 *>(coef);
+        dst[lane] = src[lane];
+        dst[64 + lane] = src[64 + lane];
+      }
+      if (lane < 52) {
+        const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
+        const int n = kSpecs[lane];
+        float mx = 0.0f;
+        for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
+        S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
       } else {
-        // ---------------- mdctStage, any block modes (encoder.js:170-349) ----------------
-        float *coef = S.u.m.a.c.coef;
-        if (emit) mdct_any_modes(band_, S.ovl, S.u.m.a.g.in, S.u.m.zz.ri.re, S.u.m.zz.ri.im, coef, M, lane, T);
-        // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
-        for (int i = lane; i < 96; i += 64) {
-          const int b = i >> 5, k = i & 31;
-          const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-          S.ovl[i] = f32(T->window[k] * (double)band_[off + Sb - 32 + k]);
-        }
-        __syncthreads();
-        // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
-        const int64_t unit = f * L.channels + ch;
-        {
-          float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
-          const float4 *src = reinterpret_cast<const float4 *>(coef);
-          dst[lane] = src[lane];
-          dst[64 + lane] = src[64 + lane];
-        }
-        if (lane < 52) {
-          const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
-          const int n = kSpecs[lane];
-          float mx = 0.0f;
-          for (int j = 0; j < n; j++) {
-            const float a = fabsf(coef[start + j]);
-            if (a > mx) mx = a;
-          }
-          S.sfi[lane] = (uint8_t)scale_factor_index(mx, T);
-        } else {
-          S.sfi[lane] = lane == 52 ? (uint8_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0;
-        }
-        __syncthreads();
-        if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-        __syncthreads();
+        S.sfi[lane] = lane == 52 ? (uint8_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0;
       }
+      __syncthreads();
+      if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+      __syncthreads();
     }
   }
 }
-
 
 // =====================================================================================================
 // transient detection as its own pipeline: blockSelectorStage (encoder.js:111-152, analysis/transient.js)
@@ -1272,12 +1192,11 @@ struct alignas(16) MdctLds {
   alignas(4) uint8_t sfi[64];
   union alignas(16) {
     struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // long-block inputs
-    struct { alignas(16) float in[1024]; } g;                                                            // any-modes staging
+    struct { alignas(16) float in[kStageFloats]; } g;                                                    // staging of frames with short blocks
     struct { alignas(16) float coef[512]; } c;
   } a;
   union alignas(16) {
     float2 z[320];
-    struct { float re[256]; float im[256]; } ri;
   } zz;
 };
 
@@ -1356,7 +1275,11 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
       mdct_long_r4(in0, S.zz.z, coef, G4, T, RT);
       __syncthreads();
     } else {
-      mdct_any_modes(S.band, S.ovl, S.a.g.in, S.zz.ri.re, S.zz.ri.im, coef, M, lane, T);
+      const MixGeometry GM = mix_geometry(lane, M);
+      mix_stage(S.band, S.ovl, S.a.g.in, M, lane, RT);
+      __syncthreads();
+      mdct_mixed_r4(S.a.g.in, S.zz.z, coef, GM, M.m0 == 0 || M.m1 == 0 || M.m2 == 0, M.m2 == 0, T, RT);
+      __syncthreads();
     }
     // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
     {
@@ -2338,8 +2261,8 @@ void c1k_launch_pcm_to_int16(const float *const *pcm, int channels, int64_t n, i
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
   const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
-  if (detect) hipLaunchKernelGGL((k_analysis_fast<true, false>), grid, block, 0, stream, L);
-  else hipLaunchKernelGGL((k_analysis_fast<false, false>), grid, block, 0, stream, L);
+  (void)detect;
+  hipLaunchKernelGGL((k_analysis_fast<false>), grid, block, 0, stream, L);
 }
 void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong, units = L.frames * L.channels;
@@ -2350,7 +2273,7 @@ void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws
 }
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
-  hipLaunchKernelGGL((k_analysis_fast<false, true>), dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+  hipLaunchKernelGGL((k_analysis_fast<true>), dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
 }
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
