@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     const int64_t slot = u + L.channels;
     const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
-    const bool have_prev = (u / L.channels - 1 >= -(int64_t)L.halo_frames);
+    const bool have_prev = ((L.channels == 2 ? u >> 1 : u) - 1 >= -(int64_t)L.halo_frames);
     pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (have_prev && lane0 < 24) pre_t = *reinterpret_cast<const float4 *>(bands_ws + ((slot - L.channels) << 9) + tail_src);
     pre_mode = modes[u];
@@ -1288,7 +1288,22 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
       dst[lane] = src[lane];
       dst[64 + lane] = src[64 + lane];
     }
-    if (lane < 52) {
+    if (mode_byte == 0) {
+      // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
+      // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
+      const bool wide = lane >= 44;
+      const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
+      const int half = wide ? (lane & 1) : 0;
+      const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
+      const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
+      float mx = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
+      mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
+      const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+      if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
+      if (lane >= 60) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60) % 3] = 0;   // modes byte (all long) and padding
+    } else if (lane < 52) {
       const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
       const int n = kSpecs[lane];
       float mx = 0.0f;
