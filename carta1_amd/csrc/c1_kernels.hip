@@ -150,35 +150,6 @@ __device__ __forceinline__ void qmf_synthesis_core(const double *w, int lane, Ta
   }
 }
 
-// ---- radix-2 DIT FFT stages over a buffer that holds several independent transforms --------------
-// fft.js:35-66.  `points` complex values in re/im (already bit-reversed per transform); transform
-// sizes are given by size_at(e).  One stage = points/2 butterflies spread over the wave; a butterfly
-// is skipped when its transform is already complete.  Float32 storage rounds after every stage.
-template <int POINTS, typename SizeAt>
-__device__ __forceinline__ void fft_stages(float *re, float *im, int lane, TablesPtr T, int max_size,
-                                           SizeAt size_at) {
-  for (int h = 1; h < max_size; h <<= 1) {
-#pragma unroll
-    for (int m = 0; m < POINTS / 128; m++) {
-      const int t = lane + 64 * m;
-      const int k = t & (h - 1);
-      const int e = ((t - k) << 1) + k;
-      const int o = e + h;
-      if (2 * h <= size_at(e)) {
-        const double tr = T->fft_tw[h - 1 + k][0], ti = T->fft_tw[h - 1 + k][1];
-        const double er = re[e], ei = im[e], orr = re[o], oi = im[o];
-        const double xr = orr * tr - oi * ti;
-        const double xi = orr * ti + oi * tr;
-        re[e] = f32(er + xr);
-        im[e] = f32(ei + xi);
-        re[o] = f32(er - xr);
-        im[o] = f32(ei - xi);
-      }
-    }
-    __syncthreads();
-  }
-}
-
 __device__ __forceinline__ int bitrev(int k, int log2n) { return (int)(__brev((unsigned)k) >> (32 - log2n)); }
 
 // findScaleFactor on binary32 bit patterns: with SF[3q] = 2^(q-21) and the two in-between fraction
@@ -273,38 +244,6 @@ struct alignas(16) MixedLds {
     } m;
   } u;
 };
-
-// (decoder) one radix-2 butterfly (fft.js:46-60) on interleaved points; H = half stride (compile time)
-// Where logical point j (0..127) of a 128-point region lives in LDS: a GF(2)-linear permutation found by
-// search (tools/lds_model.py) that makes the bit-reversed pre-twiddle stores, all seven butterfly stages
-// and the post-twiddle loads close to bank-conflict free (model cost 188 vs 364 for the identity).
-// Indices depend on the lane only and are computed once per wave, so the swizzle costs nothing per frame.
-__device__ __forceinline__ int zsw(int j) {
-  constexpr int rows[7] = {35, 70, 12, 88, 112, 32, 71};
-  int o = 0;
-#pragma unroll
-  for (int r = 0; r < 7; r++) o |= (__popc(rows[r] & j) & 1) << r;
-  return o;
-}
-// (pe/po = LDS slots of the even/odd point, tw = index of the twiddle: lane-only, see butterfly_geometry)
-template <int H>
-__device__ __forceinline__ void butterfly_geometry(int t, int &pe, int &po, int &tw) {
-  const int k = t & (H - 1);
-  const int e = ((t - k) << 1) + k;
-  pe = zsw(e);
-  po = zsw(e + H);
-  tw = H - 1 + k;
-}
-template <int H>
-__device__ __forceinline__ void fft_butterfly(float2 *z, int pe, int po, int tw, TablesPtr T) {
-  const double tr = T->fft_tw[tw][0], ti = T->fft_tw[tw][1];
-  const float2 ze = z[pe], zo = z[po];
-  const double er = ze.x, ei = ze.y, orr = zo.x, oi = zo.y;
-  const double xr = orr * tr - oi * ti;
-  const double xi = orr * ti + oi * tr;
-  z[pe] = make_float2(f32(er + xr), f32(ei + xi));
-  z[po] = make_float2(f32(er - xr), f32(ei - xi));
-}
 
 // ---- long-block MDCT core, radix-4 rounds -------------------------------------------------------------
 // The three long transforms of a frame (64, 64 and 128 complex points) run side by side: lanes 0..15 own
@@ -1823,7 +1762,7 @@ struct alignas(16) DecodeLds {
     float band[512];    // reconstructed bands: born at the overlap-add
   } cb;
   union alignas(16) {
-    struct { union alignas(16) { struct { float re[256]; float im[256]; } ri; float2 z[256]; } zz; alignas(16) float mid[512]; } m;   // IMDCT
+    struct { union alignas(16) { float2 z[320]; } zz; alignas(16) float mid[512]; } m;   // IMDCT: points (4 pad per 16), outputs
     struct { alignas(16) double w2[454]; } q2;                   // stage-2 synthesis work buffer (padded 2 per 4)
     struct { alignas(16) double w1[698]; } q1;                   // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
   } u;
@@ -1839,36 +1778,117 @@ __device__ __forceinline__ uint32_t get_bits_be(const uint32_t *words, int pos, 
   return (uint32_t)((two >> (64 - o - nb)) & ((1ull << nb) - 1ull));
 }
 
-// ---- inverse MDCT, long blocks: lane-only geometry (computed once per wave) + the shared FFT core ----
-struct IPreGeometry { int ja, jb, zi; };
-template <int NFFT, int LG, bool REV>
-__device__ __forceinline__ IPreGeometry ipre_geometry(int i, int region_offset) {
-  constexpr int n2 = 2 * NFFT;
-  const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
-  IPreGeometry g;
-  g.ja = REV ? n2 - 1 - j0 : j0;       // bands 1,2 arrive spectrally reversed (decoder.js:183-186)
-  g.jb = REV ? n2 - 1 - j1 : j1;
-  g.zi = zsw(region_offset + bitrev(i, LG));
-  return g;
+// ---- inverse MDCT in radix-4 rounds: the decoder's mirror of mdct_long_r4 / mdct_mixed_r4 -----------------------
+// Lanes 0..15 band 0, 16..31 band 1, 32..63 band 2, four points per lane; short bands stop after round B.
+// Pre-twiddle of point i reads coefficients 2i and n2-1-2i (mdct.js:161-170; bands 1,2 arrive spectrally
+// reversed, decoder.js:183-186); the post-twiddle keeps the middle half the decoder uses (decoder.js:191-199).
+struct IMixGeometry {
+  int ja[4], jb[4], pre_tab[4];
+  int za, zb, zc, zd, twb, twc, twd;
+  int post_tab[4], ox[4], oy[4];
+  bool is_long, band2;
+};
+__device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes &M) {
+  IMixGeometry G;
+  const int band = lane < 16 ? 0 : (lane < 32 ? 1 : 2);
+  const int g = lane - (band == 0 ? 0 : (band == 1 ? 16 : 32));
+  const bool lng = M.mode_of_band(band) == 0;
+  const int nfft = lng ? (band == 2 ? 128 : 64) : 16, q4 = nfft / 4, n2 = 2 * nfft;
+  const int r = lng ? bitrev(g, band == 2 ? 5 : 4) : bitrev(g & 3, 2);
+  const int blk = lng ? 0 : (g >> 2);
+  const int obase = (band == 0 ? 0 : (band == 1 ? 128 : 256)) + 32 * blk;       // coefficients in, samples out
+  const int tab_base = lng ? (band == 2 ? (int)offsetof(C1DevTables, mdct_inv512) : (int)offsetof(C1DevTables, mdct_inv256))
+                           : (int)offsetof(C1DevTables, mdct_inv64);
+  const int tw_base = (int)offsetof(C1DevTables, fft_tw);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int jp = ((j & 1) << 1) | (j >> 1);
+    const int i = r + q4 * jp;                              // position 4g+j holds point bitrev(4g+j)
+    const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
+    G.ja[j] = obase + (band > 0 ? n2 - 1 - j0 : j0);
+    G.jb[j] = obase + (band > 0 ? n2 - 1 - j1 : j1);
+    G.pre_tab[j] = tab_base + 16 * i;
+  }
+  const int pbase = band == 0 ? 0 : (band == 1 ? 64 : 128);
+  G.za = zslot(pbase + 4 * g);
+  G.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
+  G.twb = tw_base + 16 * (3 + (g & 3));
+  G.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
+  G.twc = tw_base + 16 * (15 + (g & 15));
+  G.zd = zslot(128 + (g & 31));
+  G.twd = tw_base + 16 * (63 + (g & 31));
+  G.is_long = lng;
+  G.band2 = band == 2;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = lng ? (band == 2 ? g + (j == 1 ? 64 : (j == 2 ? 32 : (j == 3 ? 96 : 0))) : g + 16 * j) : (g & 3) + 4 * j;
+    const int idx = (i < nfft / 2) ? 2 * i : (2 * (i - nfft / 2) + nfft);
+    G.post_tab[j] = tab_base + 16 * i;
+    G.ox[j] = obase + n2 - 1 - idx;
+    G.oy[j] = obase + idx;
+  }
+  return G;
 }
-// pre-twiddle of point i (mdct.js:161-170)
-__device__ __forceinline__ void imdct_pre(const float *x, const __attribute__((address_space(4))) double *tab, int i,
-                                          const IPreGeometry &g, float2 *z) {
-  const double r = -(double)x[g.ja], mm = -(double)x[g.jb];
-  const double c = tab[2 * i], sn = tab[2 * i + 1];
-  z[g.zi] = make_float2(f32(mm * sn + r * c), f32(mm * c - r * sn));
-}
-// post-twiddle of point i (mdct.js:177-208), keeping only the middle half the decoder uses (decoder.js:191-199)
-template <int NFFT>
-__device__ __forceinline__ void imdct_post(const float2 *z, int slot, const __attribute__((address_space(4))) double *tab,
-                                           int i, float *dst) {
-  constexpr int n2 = 2 * NFFT;
-  const float2 zz = z[slot];
-  const double c = tab[2 * i], sn = tab[2 * i + 1], rr = zz.x, ii = zz.y;
-  const double r1 = rr * c + ii * sn, i1 = rr * sn - ii * c;
-  const int idx = (i < NFFT / 2) ? 2 * i : (2 * (i - NFFT / 2) + NFFT);
-  dst[n2 - 1 - idx] = f32(r1);
-  dst[idx] = f32(i1);
+
+// coef: 512 dequantized coefficients; z: 320 slots; mid: 512 outputs.  any_long / band2_long are wave-uniform.
+__device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mid, const IMixGeometry &G, bool any_long,
+                                         bool band2_long, TablesPtr T, TablesRsrc R) {
+  float2 x[4];
+  {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double r = -(double)coef[G.ja[j]], mm = -(double)coef[G.jb[j]];
+      const double2 t = table_pair(R, G.pre_tab[j]);
+      x[j] = make_float2(f32(mm * t.y + r * t.x), f32(mm * t.x - r * t.y));
+    }
+    const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]);
+    const double2 w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
+    const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]);
+    if (__all(r2_unit_ok(x[0], x[1]) && r2_unit_ok(x[2], x[3]))) { r2_butterfly_unit(x[0], x[1]); r2_butterfly_unit(x[2], x[3]); }
+    else { r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0); }
+    if (__all(r2_unit_ok(x[0], x[2]))) r2_butterfly_unit(x[0], x[2]);
+    else r2_butterfly(x[0], x[2], w1);
+    r2_butterfly(x[1], x[3], w2);
+    float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+    dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+    dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+  }
+  __syncthreads();
+  {
+    float2 *p = z + G.zb;
+    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
+    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+    r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+    if (G.is_long) { p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3]; }
+  }
+  if (any_long) {
+    __syncthreads();
+    if (G.is_long) {
+      float2 *p = z + G.zc;
+      const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
+      x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
+      r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+      r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+      if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
+    }
+    if (band2_long) {
+      __syncthreads();
+      if (G.band2) {
+        const float2 *p = z + G.zd;
+        const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);
+        x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
+        r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wb);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double2 t = table_pair(R, G.post_tab[j]);
+    const double rr = x[j].x, ii = x[j].y;
+    mid[G.ox[j]] = f32(rr * t.x + ii * t.y);                // mdct.js:177-208
+    mid[G.oy[j]] = f32(rr * t.y - ii * t.x);
+  }
 }
 
 __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
@@ -1892,6 +1912,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     slot[m] = (uint32_t)b | ((uint32_t)j << 6) | ((uint32_t)(kStartShort[b] + j) << 11);
   }
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
+  const IMixGeometry IGL = imix_geometry(lane0, FrameModes{0, 0, 0});   // all-long frames
+  const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
   const int64_t f_end = (f0 + kRunFramesDecode < L.frames) ? f0 + kRunFramesDecode : L.frames;
@@ -1948,30 +1970,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     // ---------------- imdctStage (decoder.js:116-330) ----------------
     float *mid = S.u.m.mid;
     if (all_long) {
-      const IPreGeometry ig256a = ipre_geometry<64, 6, false>(lane, 0), ig256b = ipre_geometry<64, 6, true>(lane, 64);
-      const IPreGeometry ig512a = ipre_geometry<128, 7, true>(lane, 0), ig512b = ipre_geometry<128, 7, true>(lane + 64, 0);
-      int fe1, fe2, fe4, fe8, fe16, fe32, fe64, fo1, fo2, fo4, fo8, fo16, fo32, fo64, ft1, ft2, ft4, ft8, ft16, ft32, ft64;
-      butterfly_geometry<1>(lane, fe1, fo1, ft1); butterfly_geometry<2>(lane, fe2, fo2, ft2); butterfly_geometry<4>(lane, fe4, fo4, ft4);
-      butterfly_geometry<8>(lane, fe8, fo8, ft8); butterfly_geometry<16>(lane, fe16, fo16, ft16); butterfly_geometry<32>(lane, fe32, fo32, ft32);
-      butterfly_geometry<64>(lane, fe64, fo64, ft64);
-      const int ps0 = zsw(lane), ps1 = zsw(64 + lane);
-      float2 *z = S.u.m.zz.z;
-      imdct_pre(S.cb.coef, T->mdct_inv256, lane, ig256a, z);
-      imdct_pre(S.cb.coef + 128, T->mdct_inv256, lane, ig256b, z);
-      imdct_pre(S.cb.coef + 256, T->mdct_inv512, lane, ig512a, z + 128);
-      imdct_pre(S.cb.coef + 256, T->mdct_inv512, lane + 64, ig512b, z + 128);
-      __syncthreads();
-      fft_butterfly<1>(z, fe1, fo1, ft1, T); fft_butterfly<1>(z + 128, fe1, fo1, ft1, T); __syncthreads();
-      fft_butterfly<2>(z, fe2, fo2, ft2, T); fft_butterfly<2>(z + 128, fe2, fo2, ft2, T); __syncthreads();
-      fft_butterfly<4>(z, fe4, fo4, ft4, T); fft_butterfly<4>(z + 128, fe4, fo4, ft4, T); __syncthreads();
-      fft_butterfly<8>(z, fe8, fo8, ft8, T); fft_butterfly<8>(z + 128, fe8, fo8, ft8, T); __syncthreads();
-      fft_butterfly<16>(z, fe16, fo16, ft16, T); fft_butterfly<16>(z + 128, fe16, fo16, ft16, T); __syncthreads();
-      fft_butterfly<32>(z, fe32, fo32, ft32, T); fft_butterfly<32>(z + 128, fe32, fo32, ft32, T); __syncthreads();
-      fft_butterfly<64>(z + 128, fe64, fo64, ft64, T); __syncthreads();
-      imdct_post<64>(z, ps0, T->mdct_inv256, lane, mid);
-      imdct_post<64>(z, ps1, T->mdct_inv256, lane, mid + 128);
-      imdct_post<128>(z + 128, ps0, T->mdct_inv512, lane, mid + 256);
-      imdct_post<128>(z + 128, ps1, T->mdct_inv512, lane + 64, mid + 256);
+      imdct_r4(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT);
       __syncthreads();
       // overlap-add of the first 32 samples of every band (mdct.js:230-245 via decoder.js:203-232) ...
       if (lane < 32) {
@@ -1993,50 +1992,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       if (lane < 56) *reinterpret_cast<float4 *>(&S.cb.band[256 + 32 + 4 * lane]) = *reinterpret_cast<const float4 *>(&mid[256 + 16 + 4 * lane]);
     } else {
     FrameModes M{m0, m1, m2};
-    float *re = S.u.m.zz.ri.re, *im = S.u.m.zz.ri.im;
-    // pre-twiddle (mdct.js:161-170), input un-reversed for bands 1,2
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int p = lane + 64 * m;
-      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
-      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
-      const bool lng = M.mode_of_band(b) == 0;
-      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
-      const int lg = lng ? (b == 2 ? 7 : 6) : 4;
-      const int q = lng ? 0 : ((p - cbase) >> 4);
-      const int i = (p - cbase) - q * nfft;
-      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_inv512 : T->mdct_inv256) : T->mdct_inv64;
-      const int n2 = 2 * nfft;
-      const float *x = S.cb.coef + obase + q * 32;
-      const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
-      const double r = -(double)(b > 0 ? x[n2 - 1 - j0] : x[j0]);
-      const double mm = -(double)(b > 0 ? x[n2 - 1 - j1] : x[j1]);
-      const double c = tab[2 * i], s = tab[2 * i + 1];
-      const int dst = cbase + q * nfft + bitrev(i, lg);
-      re[dst] = f32(mm * s + r * c);
-      im[dst] = f32(mm * c - r * s);
-    }
-    __syncthreads();
-    fft_stages<256>(re, im, lane, T, 128, [&](int e) { return M.fft_size_at(e); });
-    // post-twiddle (mdct.js:177-208), keeping only the middle half the decoder uses (decoder.js:191-199)
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int p = lane + 64 * m;
-      const int b = p < 64 ? 0 : (p < 128 ? 1 : 2);
-      const int cbase = b == 0 ? 0 : (b == 1 ? 64 : 128), obase = b == 0 ? 0 : (b == 1 ? 128 : 256);
-      const bool lng = M.mode_of_band(b) == 0;
-      const int nfft = lng ? (b == 2 ? 128 : 64) : 16;
-      const int q = lng ? 0 : ((p - cbase) >> 4);
-      const int i = (p - cbase) - q * nfft;
-      const __attribute__((address_space(4))) double *tab = lng ? (b == 2 ? T->mdct_inv512 : T->mdct_inv256) : T->mdct_inv64;
-      const int n2 = 2 * nfft, n4 = nfft;
-      const double c = tab[2 * i], s = tab[2 * i + 1], rr = re[p], ii = im[p];
-      const double r1 = rr * c + ii * s, i1 = rr * s - ii * c;
-      const int idx = (i < nfft / 2) ? 2 * i : (2 * (i - nfft / 2) + n4);
-      float *dst = mid + obase + q * 32;
-      dst[n2 - 1 - idx] = f32(r1);
-      dst[idx] = f32(i1);
-    }
+    const IMixGeometry IG = imix_geometry(lane, M);
+    imdct_r4(S.cb.coef, S.u.m.zz.z, mid, IG, m0 == 0 || m1 == 0 || m2 == 0, m2 == 0, T, RT);
     __syncthreads();
     // overlap-add (mdct.js:230-245 via decoder.js:203-232 long / :262-300 short)
 #pragma unroll
