@@ -368,3 +368,44 @@ def test_signed_zero_and_non_finite_pcm_take_the_reference_arithmetic(ctx):
         got = ctx.encode([pcm], c1.EncoderOptions(opts))
         bad = first_diff(got, want)
         assert len(bad) == 0, (opts, bad)
+
+
+@pytest.mark.parametrize('modes', [[0, 0, 3], [2, 2, 0], [2, 0, 0], [0, 2, 3]])
+def test_every_long_short_combination(ctx, modes):
+    """Each band is long or short on its own: the mixed radix-4 cores of the encoder and the decoder."""
+    import carta1_amd as c1
+    chs = [O.gen_white(41, 300 * 512), O.gen_pinkT(42, 300 * 512)]
+    want, _ = O.encode_stream(chs, fixed_modes=modes)
+    got = ctx.encode(chs, c1.EncoderOptions({'fixedBlockModes': modes}))
+    assert first_diff(got, want).size == 0, first_diff(got, want)
+    pcm_want, _ = O.decode_stream(want, 2)
+    pcm_got = ctx.decode(want, 2)
+    for c in range(2):
+        assert np.array_equal(pcm_got[c].view(np.uint32), pcm_want[c].view(np.uint32))
+
+
+def test_internal_chunking_is_invisible():
+    """The library cuts a batch into chunks of C1_CHUNK_FRAMES; a context with tiny chunks must produce the same
+    bytes (the detection pipeline carries frame -1 of every chunk in its workspace)."""
+    import carta1_amd as c1
+    chs = [O.gen_pinkT(7, 500 * 512), O.gen_pinkT(8, 500 * 512)]
+    old = os.environ.get('C1_CHUNK_FRAMES')
+    os.environ['C1_CHUNK_FRAMES'] = '96'
+    try:
+        small = c1.Context(0)
+    finally:
+        if old is None:
+            del os.environ['C1_CHUNK_FRAMES']
+        else:
+            os.environ['C1_CHUNK_FRAMES'] = old
+    big = c1.Context(0)
+    try:
+        for opts in ({}, {'fixedBlockModes': [0, 0, 0]}, {'fixedBlockModes': [2, 2, 3]}, {'transientThresholdLow': 0.3}):
+            a = small.encode(chs, c1.EncoderOptions(opts))
+            b = big.encode(chs, c1.EncoderOptions(opts))
+            assert np.array_equal(a, b), opts
+        want, _ = O.encode_stream(chs)
+        assert np.array_equal(small.encode(chs, c1.EncoderOptions()), want)
+    finally:
+        small.close()
+        big.close()
