@@ -14,7 +14,9 @@ starts r*1M frames in, by an exact xorshift jump): the frame batch shards with n
 Rank 0 prints ONE JSON line.  `roofline` prices the slowest kernel of the pass against the 8 TB/s HBM
 peak using the ALGORITHMIC bytes of the path (2048 B PCM read + 212 B unit written per mono frame =
 4520 B per stereo frame), with that kernel's launch durations measured by HIP events on
-the stream the library launches on.  `cpu_baseline` times the CPU oracle (a C restatement of the
+the stream the library launches on.  `roofline_valu` (extra) prices the same kernel against what actually
+bounds it: vector-ALU issue cycles of its measured instruction mix (fp64 arithmetic is the reference's semantics).
+`cpu_baseline` times the CPU oracle (a C restatement of the
 reference, single thread) on a bounded sample of the same workload on this host.
 """
 import argparse
@@ -175,20 +177,32 @@ def main():
     if rank == 0:
         total_frames = frames * world * args.steps
         value = total_frames / elapsed
-        kernel_names = {'analysis': 'k_analysis_fast<false, true>' if modes == [0, 0, 0] else ('k_analysis_fast<true, false>' if modes is None else 'k_analysis_fast<false, false>'),
+        kernel_names = {'analysis': 'k_analysis_fast<true>' if modes == [0, 0, 0] else ('k_detect_features+k_detect_decide+k_mdct_bands' if modes is None else 'k_analysis_fast<false>'),
                         'allocate': 'k_alloc_first+k_alloc_rest+k_alloc_select', 'pack': 'k_pack', 'decode': 'k_decode'}
         dom = max(kernel_ms, key=lambda k: kernel_ms[k]['ms_per_step'])
         dom_ms, dom_n = kernel_ms[dom]['ms_per_step'], max(1, kernel_ms[dom]['launches_per_step'])
         frames_per_launch = frames / dom_n
         avg_launch_s = dom_ms / dom_n / 1e3
         achieved = BYTES_PER_STEREO_FRAME * frames_per_launch / avg_launch_s / 1e9
-        traffic = None
+        # PMC-derived figures of the same kernel on the same workload (profiles/pmc_traffic.json, tools/make_pmc_json.py):
+        # HBM bytes per launch, and the VALU issue cycles its instruction mix needs (4 per fp64-rate, 2 per 32-bit
+        # instruction of a wave64); only valid for the configuration they were collected on (config 2)
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and modes == [0, 0, 0] and not args.decode and args.signal == 'white':
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
+                pmc = json.load(open(tpath))
+                scale = frames_per_launch * 2 / pmc['units_per_launch']
+                traffic = pmc.get(dom, {}).get('hbm_bytes_per_launch')
+                traffic = traffic * scale if traffic is not None else None
+                cyc = pmc.get(dom, {}).get('valu_issue_cycles_per_launch')
+                if cyc is not None:
+                    peak = 256 * 4 * 2.4e9                      # SIMDs x nominal clock: issue cycles per second
+                    valu = {'bound': 'valu-issue', 'achieved': cyc * scale / avg_launch_s, 'peak': peak, 'unit': 'SIMD cycles/s',
+                            'frac': cyc * scale / avg_launch_s / peak,
+                            'note': 'fp64 arithmetic (the reference semantics) makes the kernel VALU bound, not HBM bound: DESIGN.md 5'}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         line = {
             'metric': 'atrac1_stereo_frames_per_s_%s' % ('decode' if args.decode else 'encode'),
             'value': value, 'unit': 'stereo frames/s', 'n_gpus': world, 'steps': args.steps,
@@ -204,6 +218,7 @@ def main():
                          'algorithmic_bytes_per_stereo_frame': BYTES_PER_STEREO_FRAME,
                          'stereo_frames_per_launch': frames_per_launch, 'avg_launch_ms': dom_ms / dom_n,
                          'whole_pass_frac': BYTES_PER_STEREO_FRAME * value / world / 1e9 / HBM_PEAK_GBS},
+            'roofline_valu': valu,
             'kernels_ms_per_step': {k: v['ms_per_step'] for k, v in kernel_ms.items()},
         }
         if world == 1 and args.cpu_sample > 0 and not args.decode:
