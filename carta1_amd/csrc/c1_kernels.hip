@@ -55,27 +55,28 @@ __device__ __forceinline__ TablesPtr tables_for_this_frame(const C1DevTables *p)
 namespace {
 
 // ---- format tables: codec/core/constants.js:29-52, :141-143 -----------------------------------
-__constant__ uint8_t kSpecs[52] = {8, 8, 8, 8, 4,  4,  4,  4,  8,  8,  8,  8,  6,  6,  6,  6,  6,  6,
+__constant__ const uint8_t kSpecs[52] = {8, 8, 8, 8, 4,  4,  4,  4,  8,  8,  8,  8,  6,  6,  6,  6,  6,  6,
                                    6, 6, 6, 6, 6,  6,  7,  7,  7,  7,  9,  9,  9,  9,  10, 10, 10, 10,
                                    12, 12, 12, 12, 12, 12, 12, 12, 20, 20, 20, 20, 20, 20, 20, 20};
-__constant__ uint16_t kStartLong[52] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,
+__constant__ const uint16_t kStartLong[52] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,
                                         86,  92,  98,  104, 110, 116, 122, 128, 134, 140, 146, 152, 159,
                                         166, 173, 180, 189, 198, 207, 216, 226, 236, 246, 256, 268, 280,
                                         292, 304, 316, 328, 340, 352, 372, 392, 412, 432, 452, 472, 492};
-__constant__ uint16_t kStartShort[52] = {0,   32,  64,  96,  8,   40,  72,  104, 12,  44,  76,  108, 20,
+__constant__ const uint16_t kStartShort[52] = {0,   32,  64,  96,  8,   40,  72,  104, 12,  44,  76,  108, 20,
                                          52,  84,  116, 26,  58,  90,  122, 128, 160, 192, 224, 134, 166,
                                          198, 230, 141, 173, 205, 237, 150, 182, 214, 246, 256, 288, 320,
                                          352, 384, 416, 448, 480, 268, 300, 332, 364, 396, 428, 460, 492};
 // first coefficient slot (BFU-major order) of each BFU = prefix sum of kSpecs
-__constant__ uint16_t kBfuFirst[53] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,  86,
+__constant__ const uint16_t kBfuFirst[53] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,  86,
                                        92,  98,  104, 110, 116, 122, 128, 134, 140, 146, 152, 159, 166, 173,
                                        180, 189, 198, 207, 216, 226, 236, 246, 256, 268, 280, 292, 304, 316,
                                        328, 340, 352, 372, 392, 412, 432, 452, 472, 492, 512};
-__constant__ uint8_t kAmounts[8] = {20, 28, 32, 36, 40, 44, 48, 52};
+// BFU_AMOUNTS {20, 28, 32, 36, 40, 44, 48, 52} (constants.js) as arithmetic: a lane-varying lookup would be a global load, and waiting for it (vmcnt is in order)
+// also waits for every prefetch issued before it
+__device__ __forceinline__ int bfu_amount(int index) { return index == 0 ? 20 : 24 + 4 * index; }
 
 __device__ __forceinline__ int wl_bits(int wl) { return wl == 0 ? 0 : wl + 1; }  // WORD_LENGTH_BITS
 __device__ __forceinline__ int band_of_bfu(int b) { return b >= 36 ? 2 : (b >= 20 ? 1 : 0); }
-__device__ __forceinline__ int bfu_start(int b, int mode) { return mode == 0 ? kStartLong[b] : kStartShort[b]; }
 // BFU that owns coefficient slot p (BFU-major order); sizes are piecewise constant
 __device__ __forceinline__ int bfu_of_slot(int p) {
   if (p < 32) return p >> 3;
@@ -192,6 +193,31 @@ struct FrameModes {
     return mode_of_band(b) != 0 ? 16 : (b == 2 ? 128 : 64);
   }
 };
+
+// scale factors of an all-long frame (bitallocation.js:80-90): lanes 0..43 take BFUs 0..43 (<= 12 coefficients),
+// lanes 44..59 take one half (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are
+// combined.  The lane's slice is fixed, so it is looked up once per wave (a lookup inside the frame loop is a
+// global load whose wait also waits for the frame's stores).
+struct SfLong { int cnt, src, b; bool wide, store; };
+__device__ __forceinline__ SfLong sf_long_geometry(int lane) {
+  SfLong g;
+  g.wide = lane >= 44;
+  g.b = g.wide ? 44 + ((lane - 44) >> 1) : lane;
+  const int half = g.wide ? (lane & 1) : 0;
+  g.cnt = lane < 60 ? (g.wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
+  g.src = kStartLong[lane < 60 ? g.b : 0] + 10 * half;
+  g.store = lane < 60 && (!g.wide || half == 0);
+  return g;
+}
+__device__ __forceinline__ void sf_long(const float *coef, uint8_t *sfi_out, const SfLong &g, TablesPtr T) {
+  const float *src = coef + g.src;
+  float mx = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < g.cnt ? j : g.cnt - 1]));
+  mx = fmaxf(mx, g.wide ? __shfl_xor(mx, 1) : 0.0f);
+  const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+  if (g.store) sfi_out[g.b] = (uint8_t)sfi;
+}
 
 // =====================================================================================================
 // k_analysis_fast : QMF -> block selection -> MDCT -> scale factors, one wave per run of frames
@@ -618,6 +644,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_analysis_fast(C1EncodeLaunch L) 
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   // lane-only geometry of the long-block MDCT core, computed once (everything else is re-derived per frame)
   const R4Geometry G4 = r4_geometry(lane0);
+  const SfLong SFL = sf_long_geometry(lane0);
+  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
   const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
@@ -737,22 +765,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_analysis_fast(C1EncodeLaunch L) 
         dst[lane] = src[lane];
         dst[64 + lane] = src[64 + lane];
       }
-      {
-        // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
-        // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
-        const bool wide = lane >= 44;
-        const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
-        const int half = wide ? (lane & 1) : 0;
-        const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
-        const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
-        float mx = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
-        mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
-        const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
-        if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
-        if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
-      }
+      sf_long(coef, S.sfi, SFL, T);
+      if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
       __syncthreads();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
       __syncthreads();
@@ -783,8 +797,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_analysis_fast(C1EncodeLaunch L) 
         dst[64 + lane] = src[64 + lane];
       }
       if (lane < 52) {
-        const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
-        const int n = kSpecs[lane];
+        const int start = M.mode_of_band(band_of_bfu(lane)) == 0 ? my_long : my_short;
+        const int n = my_size;
         float mx = 0.0f;
         for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
         S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
@@ -1146,6 +1160,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const R4Geometry G4 = r4_geometry(lane0);
+  const SfLong SFL = sf_long_geometry(lane0);
+  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
   const TablesRsrc RT = tables_rsrc(L.tables);
   const int64_t units = L.frames * L.channels;
   // tails of the previous frame: lane < 24 loads four samples of band lane / 8
@@ -1228,23 +1244,11 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
       dst[64 + lane] = src[64 + lane];
     }
     if (mode_byte == 0) {
-      // max |coef| per BFU: lanes 0..43 take BFUs 0..43 (<= 12 coefficients), lanes 44..59 take one half
-      // (10 coefficients) of BFUs 44..51 each; 12 clamped reads per lane, then the halves are combined
-      const bool wide = lane >= 44;
-      const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
-      const int half = wide ? (lane & 1) : 0;
-      const int cnt = lane < 60 ? (wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
-      const float *src = coef + kStartLong[lane < 60 ? b : 0] + 10 * half;
-      float mx = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < cnt ? j : cnt - 1]));
-      mx = fmaxf(mx, wide ? __shfl_xor(mx, 1) : 0.0f);
-      const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
-      if (lane < 60 && (!wide || half == 0)) S.sfi[b] = (uint8_t)sfi;
+      sf_long(coef, S.sfi, SFL, T);
       if (lane >= 60) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60) % 3] = 0;   // modes byte (all long) and padding
     } else if (lane < 52) {
-      const int start = bfu_start(lane, M.mode_of_band(band_of_bfu(lane)));
-      const int n = kSpecs[lane];
+      const int start = M.mode_of_band(band_of_bfu(lane)) == 0 ? my_long : my_short;
+      const int n = my_size;
       float mx = 0.0f;
       for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
       S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
@@ -1515,7 +1519,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L) {
     load_sfi(L.side, unit, sf);
     uint64_t r0, r1, r2, r3;
     double total;
-    run_candidate(heap + lane, kAmounts[c], sf, O, live, r0, r1, r2, r3, total);
+    run_candidate(heap + lane, bfu_amount(c), sf, O, live, r0, r1, r2, r3, total);
     if (live) store_candidate(L.cand, unit, c, total < __builtin_huge_val() ? total : __builtin_huge_val(), r0, r1, r2, r3);
   }
 }
@@ -1668,7 +1672,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L)
     const uint32_t a7 = h0.al7;
     const bool fallback = (a7 >> 27) & 1;
     const int amount = (int)(a7 >> 28) & 7;
-    const int n = kAmounts[amount];
+    const int n = bfu_amount(amount);
     const int modes = (int)(__shfl(h0.sd_q, 13) & 0xff);
     const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
     if (lane < 56) S.words[lane] = 0;
@@ -1934,7 +1938,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     __syncthreads();
     const uint32_t header = S.words[0] >> 16;
     const int m0 = 2 - (int)((header >> 14) & 3), m1 = 2 - (int)((header >> 12) & 3), m2 = 3 - (int)((header >> 10) & 3);
-    const int n = kAmounts[(header >> 5) & 7];
+    const int n = bfu_amount((header >> 5) & 7);
     int wl = 0, sfi = 0;
     if (lane < n) {
       wl = (int)get_bits_be(S.words, 16 + 4 * lane, 4);
