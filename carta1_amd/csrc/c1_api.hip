@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -123,6 +124,23 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
     const uint32_t frac = u & 0x7fffffu, want = i % 3 == 0 ? 0u : (i % 3 == 1 ? d->sf_m1 : d->sf_m2);
     const bool exact_pow2 = i % 3 != 0 || (double)std::ldexp(1.0f, want_e) == t.scale_factors[i];
     if (e != want_e || frac != want || !exact_pow2) d->sf_fast = 0;
+  }
+  // dequantize (quantization.js:65-78): Float32((q * SF) / range).  One correctly rounded reciprocal, a multiply
+  // and two FMAs give the correctly rounded quotient (Markstein); rather than rely on the theorem's side
+  // conditions, compare against the division for every input the decoder can meet with this table.
+  d->dq_fast = 1;
+  for (int wl = 1; wl < 16 && d->dq_fast; wl++) {
+    const int bits = wl + 1;
+    const double range = (double)((1 << (bits - 1)) - 1), y = 1.0 / range;
+    d->inv_range[wl] = y;
+    for (int s = 1; s < 64 && d->dq_fast; s++) {
+      const double sf = t.scale_factors[s];
+      for (int q = -(1 << (bits - 1)); q < (1 << (bits - 1)); q++) {
+        const double a = (double)q * sf;
+        const double q0 = a * y, r = std::fma(-q0, range, a), fast = std::fma(r, y, q0), exact = a / range;
+        if (!(fast == exact) || std::signbit(fast) != std::signbit(exact)) { d->dq_fast = 0; break; }
+      }
+    }
   }
 }
 
@@ -508,6 +526,19 @@ int c1_set_tables(const c1_tables *tables) {
     if (!std::isfinite(p[i])) return fail(C1_ERR_ARG, "table entry %zu is not finite", i);
   g_tables = *tables;
   g_tables_custom = true;
+  return C1_OK;
+}
+
+int c1_table_fast_paths(int *scale_factor_bits, int *dequant_reciprocal) {
+  c1_tables t;
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    if (g_tables_custom) t = g_tables; else default_tables(&t);
+  }
+  std::unique_ptr<C1DevTables> d(new C1DevTables);
+  build_device_tables(t, d.get());
+  if (scale_factor_bits) *scale_factor_bits = d->sf_fast;
+  if (dequant_reciprocal) *dequant_reciprocal = d->dq_fast;
   return C1_OK;
 }
 

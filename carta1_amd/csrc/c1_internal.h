@@ -26,7 +26,11 @@ struct C1DevTables {
   // shares them (always true for the reference's table); sf_fast = 0 selects the table compare
   uint32_t sf_m1, sf_m2;
   int32_t sf_fast;
-  int32_t pad_;
+  // dequantization (q * SF) / range as q0 = a*y, r = fma(-q0, range, a), fma(r, y, q0) with y = RN(1/range)
+  // (Markstein): dq_fast = 1 when the host has checked it against the division for every (bits, sfi, q) of
+  // the installed table (8.3 M cases), else the kernel divides
+  int32_t dq_fast;
+  double inv_range[16];      // RN(1 / (2^(wl) - 1)) by word-length index wl = 1..15
 };
 
 // ---- per-call encoder options in device form ---------------------------------------------------

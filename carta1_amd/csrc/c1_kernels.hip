@@ -1761,6 +1761,8 @@ struct alignas(16) DecodeLds {
   float tail[48];       // last 16 IMDCT samples per band (imdctOverlap tails, decoder.js:227-230)
   uint32_t words[56];   // the unit as big-endian words
   uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
+  double sf_tab[64];    // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
+  double inv_tab[16];   // coefficient would cost a cache round trip each)
   union alignas(16) {
     float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
     float band[512];    // reconstructed bands: born at the overlap-add
@@ -1907,6 +1909,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   for (int i = lane; i < 39; i += 64) S.dhi[i] = 0.0f;
   for (int i = lane; i < 48; i += 64) S.tail[i] = 0.0f;
   if (lane < 3) S.words[53 + lane] = 0u;
+  S.sf_tab[lane] = C1_TABLES(L.tables)->scale_factors[lane];
+  if (lane < 16) S.inv_tab[lane] = C1_TABLES(L.tables)->inv_range[lane];
   // lane-only geometry, computed once per wave
   uint32_t slot[8];                                  // BFU(6) | index inside the BFU(5) << 6 | short-block position(9) << 11
 #pragma unroll
@@ -1965,7 +1969,16 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       const uint32_t raw = get_bits_be(S.words, (int)(dsc >> 11) + sj * bits, bits);
       const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;     // bitstream.js:78-82
       const int32_t range = (1 << (bits - 1)) - 1;
-      const float v = sf != 0 ? f32(((double)q * T->scale_factors[sf]) / (double)range) : 0.0f;   // quantization.js:65-78
+      float v = 0.0f;                                                                               // quantization.js:65-78
+      if (sf != 0) {
+        const double a = (double)q * S.sf_tab[sf];
+        if (T->dq_fast) {
+          const double y = S.inv_tab[bits - 1], q0 = a * y;
+          v = f32(__builtin_fma(__builtin_fma(-q0, (double)range, a), y, q0));                  // == a / range (checked on the host)
+        } else {
+          v = f32(a / (double)range);
+        }
+      }
       const int mode = sb >= 36 ? m2 : (sb >= 20 ? m1 : m0);
       S.cb.coef[mode == 0 ? lane + 64 * m : (int)(slot[m] >> 11)] = v;
     }

@@ -89,6 +89,12 @@ int c1_set_tables(const c1_tables *tables);      /* NULL restores defaults; appl
 /* fills biased_scale_factors for allocationBias == 1 (exact copy, bitallocation.js:51-52) and sets
  * threshold 1.0 / detection on: the EncoderOptions defaults (options.js:17-23) */
 int c1_default_encode_options(c1_encode_options *out);
+/* Diagnostics (host only, no device needed): which table-dependent shortcuts the kernels will take with the
+ * tables currently installed.  Both are verified on the host against the plain formulation for the whole input
+ * domain when tables are installed, and the kernels fall back to it when a check fails:
+ *  scale_factor_bits  findScaleFactor (bitallocation.js:290-299) from the binary32 bit pattern
+ *  dequant_reciprocal dequantize's (q * SF) / range (quantization.js:65-78) as multiply + two FMAs */
+int c1_table_fast_paths(int *scale_factor_bits, int *dequant_reciprocal);
 
 /* ---- contexts ------------------------------------------------------------------------- */
 int c1_ctx_create(int device, void *hip_stream /* hipStream_t or NULL = own stream */, c1_ctx **out);

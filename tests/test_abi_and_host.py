@@ -145,3 +145,23 @@ def test_sound_unit_fields_round_trip_and_match_reference():
         assert list(o.q)[:sum(codec.SPECS_PER_BFU[:o.nbfu])] == [v for b in f['quantizedCoefficients'] for v in b]
     with pytest.raises(ValueError, match='Frame must be 212 bytes'):
         codec.deserialize_frame(b'123')
+
+
+def test_table_dependent_shortcuts_are_verified_for_the_default_tables():
+    """The kernels read findScaleFactor off the binary32 bit pattern and dequantize with a reciprocal + two FMAs
+    only when the host has checked those forms over their whole input domain for the installed tables."""
+    from carta1_amd import capi
+    lib = capi.load()
+    a, b = C.c_int(-1), C.c_int(-1)
+    assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0
+    assert (a.value, b.value) == (1, 1)
+    t = capi.Tables()
+    assert lib.c1_get_default_tables(C.byref(t)) == 0
+    t.scale_factors[10] *= 1.0000001            # no longer 2^(i/3 - 21): the bit-pattern form must be refused
+    try:
+        assert lib.c1_set_tables(C.byref(t)) == 0
+        assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0
+        assert a.value == 0
+    finally:
+        lib.c1_set_tables(None)
+    assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (1, 1)
