@@ -380,14 +380,17 @@ __device__ __forceinline__ void r2_butterfly_unit(float2 &e, float2 &o) {
 // memory with `in`: the inputs are dead once round A has read them)
 __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R) {
   float2 x[4];
+  // the lane-varying table values of the frame are requested up front: the loads are in flight while round A
+  // reads its inputs, instead of one cache round trip in front of every round
+  const double2 t0 = table_pair(R, G.pre_tab[0]), t1 = table_pair(R, G.pre_tab[1]);
+  const double2 t2 = table_pair(R, G.pre_tab[2]), t3 = table_pair(R, G.pre_tab[3]);
+  const double2 wBa = table_pair(R, G.twb), wBb = table_pair(R, G.twb + 64), wBc = table_pair(R, G.twb + 128);
   // ---- round A: pre-twiddle + stages 1, 2 ----
   {
     const float a0 = in[G.ia[0]], c0 = in[G.ic[0]], b0 = in[G.ib0], d0 = in[G.id0];
     const float a1 = in[G.ia[1]], c1 = in[G.ic[1]];
     const float a2 = in[G.ia[2]], c2 = in[G.ic[2]];
     const float a3 = in[G.ia[3]], c3 = in[G.ic[3]], b3 = in[G.ib3], d3 = in[G.id3];
-    const double2 t0 = table_pair(R, G.pre_tab[0]), t1 = table_pair(R, G.pre_tab[1]);
-    const double2 t2 = table_pair(R, G.pre_tab[2]), t3 = table_pair(R, G.pre_tab[3]);
     // the long-block input is zero outside [N/4 - 16 .. 3N/4 + 16): for the points of positions 4g+1 and 4g+2
     // the operands b and d are those zeros for every lane, and x - (+0) == x, so only "+ 0.0" remains
     const double r0 = (double)a0 + (double)b0, m0 = (double)c0 - (double)d0;      // first half:  r = a + b, m = c - d
@@ -411,21 +414,26 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
     dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
     dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
   }
+  // (the twiddles of rounds C and D take the registers the pre-twiddle pairs just left)
+  const double2 wCa = table_pair(R, G.twc), wCb = table_pair(R, G.twc + 256), wCc = table_pair(R, G.twc + 512);
+  const double2 wDa = table_pair(R, G.twd), wDb = table_pair(R, G.twd + 512);
   __syncthreads();
   // ---- round B: stages 4, 8 ----
   {
     float2 *p = z + G.zb;
-    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    const double2 wa = wBa, wb = wBb, wc = wBc;
     x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
     r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
     r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
     p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3];
   }
+  const double2 p0 = table_pair(R, G.post_tab[0]), p1 = table_pair(R, G.post_tab[1]);
+  const double2 p2 = table_pair(R, G.post_tab[2]), p3 = table_pair(R, G.post_tab[3]);
   __syncthreads();
   // ---- round C: stages 16, 32 ----
   {
     float2 *p = z + G.zc;
-    const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
+    const double2 wa = wCa, wb = wCb, wc = wCc;
     x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
     r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
     r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
@@ -435,14 +443,14 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
   // ---- round D: stage 64 of the 128-point transform ----
   if (G.band2) {
     const float2 *p = z + G.zd;
-    const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);
+    const double2 wa = wDa, wb = wDb;
     x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
     r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wb);
   }
   // ---- post-twiddle + spectrum reversal ----
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const double2 t = table_pair(R, G.post_tab[j]);
+    const double2 t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
     const double rr = x[j].x, ii = x[j].y;
     coef[G.cx[j]] = f32(-rr * t.x - ii * t.y);
     coef[G.cy[j]] = f32(-rr * t.y + ii * t.x);
@@ -623,7 +631,7 @@ __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, flo
 }
 
 template <bool ALL_LONG>
-__global__ __launch_bounds__(C1_WAVE, 3) void k_analysis_fast(C1EncodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1EncodeLaunch L) {
   using Lds = typename std::conditional<ALL_LONG, LongLds, MixedLds>::type;
   __shared__ Lds S;
   float *band_;                                        // low128 | mid128 | high256 of the current frame, raw
