@@ -571,11 +571,15 @@ __device__ __forceinline__ void mix_stage(const float *band_, const float *ovl_,
 __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, float *coef, const MixGeometry &G, bool any_long,
                                               bool band2_long, TablesPtr T, TablesRsrc R) {
   float2 x[4];
+  // table values are requested one round ahead of their use (see mdct_long_r4)
+  const double2 pt0 = table_pair(R, G.pre_tab[0]), pt1 = table_pair(R, G.pre_tab[1]);
+  const double2 pt2 = table_pair(R, G.pre_tab[2]), pt3 = table_pair(R, G.pre_tab[3]);
+  const double2 wBa = table_pair(R, G.twb), wBb = table_pair(R, G.twb + 64), wBc = table_pair(R, G.twb + 128);
   {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const double a = stage[G.ia[j]], b = stage[G.ib[j]], c = stage[G.ic[j]], d = stage[G.id[j]];
-      const double2 t = table_pair(R, G.pre_tab[j]);
+      const double2 t = j == 0 ? pt0 : (j == 1 ? pt1 : (j == 2 ? pt2 : pt3));
       const double r = (j & 1) ? a - b : a + b;             // mdct.js:84-99
       const double m = (j & 1) ? c + d : c - d;
       x[j] = make_float2(f32(r * t.x + m * t.y), f32(m * t.x - r * t.y));
@@ -592,10 +596,12 @@ __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, flo
     dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
     dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
   }
+  const double2 p0 = table_pair(R, G.post_tab[0]), p1 = table_pair(R, G.post_tab[1]);
+  const double2 p2 = table_pair(R, G.post_tab[2]), p3 = table_pair(R, G.post_tab[3]);
   __syncthreads();
   {
     float2 *p = z + G.zb;
-    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    const double2 wa = wBa, wb = wBb, wc = wBc;
     x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
     r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
     r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
@@ -623,7 +629,7 @@ __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, flo
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const double2 t = table_pair(R, G.post_tab[j]);
+    const double2 t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
     const double rr = x[j].x, ii = x[j].y;
     coef[G.cx[j]] = f32(-rr * t.x - ii * t.y);
     coef[G.cy[j]] = f32(-rr * t.y + ii * t.x);
