@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libcarta1_hip.so')
+# C1_LIB: another build of the same library (A/B timing of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get('C1_LIB') or os.path.join(HERE, 'lib', 'libcarta1_hip.so')
 
 FRAME = 512
 UNIT_BYTES = 212

@@ -1006,6 +1006,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
         x[j] = make_float2(src[jr * tS], 0.0f);
       }
     }
+    // twiddles of round B are requested before round A computes, those of round C before round B
+    const double2 w8 = table_pair(RT, t_twb), w16a = table_pair(RT, t_twb + 128), w16b = table_pair(RT, t_twb + 256);
+    const double2 w32a = table_pair(RT, t_twb + 384), w32b = table_pair(RT, t_twb + 512);
+    const double2 w32c = table_pair(RT, t_twb + 640), w32d = table_pair(RT, t_twb + 768);
     tfft_round_a(x, T);
     float2 *z = S.u.t.z;
     {
@@ -1016,9 +1020,6 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
     __syncthreads();
     {
       float2 *p = z + t_zb;                                    // stages 8, 16, 32 on the points p + 8j
-      const double2 w8 = table_pair(RT, t_twb), w16a = table_pair(RT, t_twb + 128), w16b = table_pair(RT, t_twb + 256);
-      const double2 w32a = table_pair(RT, t_twb + 384), w32b = table_pair(RT, t_twb + 512);
-      const double2 w32c = table_pair(RT, t_twb + 640), w32d = table_pair(RT, t_twb + 768);
 #pragma unroll
       for (int j = 0; j < 8; j++) x[j] = p[9 * j];
       r2_butterfly(x[0], x[1], w8); r2_butterfly(x[2], x[3], w8); r2_butterfly(x[4], x[5], w8); r2_butterfly(x[6], x[7], w8);
@@ -1027,6 +1028,9 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
 #pragma unroll
       for (int j = 0; j < 8; j++) p[9 * j] = x[j];
     }
+    const double2 wDa = table_pair(RT, t_twd), wDb = table_pair(RT, t_twd + 512);
+    const double2 wC0 = table_pair(RT, t_twc), wC1 = table_pair(RT, t_twc + t_twc_stride);
+    const double2 wC2 = table_pair(RT, t_twc + 2 * t_twc_stride), wC3 = table_pair(RT, t_twc + 3 * t_twc_stride);
     __syncthreads();
     float mg[4];
     {
@@ -1036,12 +1040,11 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
 #pragma unroll
       for (int t = 0; t < 8; t++) x[t] = p[t * t_zc_stride];
       if (tband == 2) {
-        const double2 wa = table_pair(RT, t_twd), wb = table_pair(RT, t_twd + 512);
-        r2_butterfly(x[0], x[2], wa); r2_butterfly(x[1], x[3], wb); r2_butterfly(x[4], x[6], wa); r2_butterfly(x[5], x[7], wb);
+        r2_butterfly(x[0], x[2], wDa); r2_butterfly(x[1], x[3], wDb); r2_butterfly(x[4], x[6], wDa); r2_butterfly(x[5], x[7], wDb);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const float2 e = r2_butterfly_e(x[i], x[i + 4], table_pair(RT, t_twc + i * t_twc_stride));
+        const float2 e = r2_butterfly_e(x[i], x[i + 4], i == 0 ? wC0 : (i == 1 ? wC1 : (i == 2 ? wC2 : wC3)));
         const double r = e.x, im = e.y;
         mg[i] = f32(sqrt(r * r + im * im));
       }
@@ -1181,6 +1184,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   // tails of the previous frame: lane < 24 loads four samples of band lane / 8
   const int tail_band = lane0 >> 3, tail_k = 4 * (lane0 & 7);
   const int tail_src = (tail_band == 0 ? 96 : (tail_band == 1 ? 224 : 480)) + tail_k;
+  // window values the lane needs every unit: fixed per lane, read once
+  const double wt0 = C1_TABLES(L.tables)->window[tail_k & 31], wt1 = C1_TABLES(L.tables)->window[(tail_k + 1) & 31];
+  const double wt2 = C1_TABLES(L.tables)->window[(tail_k + 2) & 31], wt3 = C1_TABLES(L.tables)->window[(tail_k + 3) & 31];
+  const double win_hi = C1_TABLES(L.tables)->window[31 - (lane0 & 31)];
   int64_t unit = blockIdx.x;
   if (unit >= units) return;
   float4 pre_a, pre_b, pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1205,10 +1212,9 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     reinterpret_cast<float4 *>(S.band)[64 + lane] = b;
     if (lane < 24) {
       // mdctOverlap of the previous frame (applyTailWindowing, encoder.js:309-316): W[k] * tail sample
-      const int k = 4 * (lane & 7);
       float4 o;
-      o.x = f32(T->window[k] * (double)t.x); o.y = f32(T->window[k + 1] * (double)t.y);
-      o.z = f32(T->window[k + 2] * (double)t.z); o.w = f32(T->window[k + 3] * (double)t.w);
+      o.x = f32(wt0 * (double)t.x); o.y = f32(wt1 * (double)t.y);
+      o.z = f32(wt2 * (double)t.z); o.w = f32(wt3 * (double)t.w);
       reinterpret_cast<float4 *>(S.ovl)[lane] = o;
     }
     __syncthreads();
@@ -1219,7 +1225,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
       float *in0 = S.a.i.in0, *in1 = S.a.i.in1, *in2 = S.a.i.in2;
       const float *band_ = S.band;
       if (lane < 32) {
-        const double w_hi = T->window[31 - lane];
+        const double w_hi = win_hi;
         const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
         in0[48 + lane] = S.ovl[lane]; in1[48 + lane] = S.ovl[32 + lane]; in2[112 + lane] = S.ovl[64 + lane];
         in0[80 + 96 + lane] = f32(x0 * w_hi);
