@@ -436,7 +436,6 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.cand = ctx->d_cand[p];
     L.work_count = ctx->d_work[p];
     L.work_list = ctx->d_work[p] + 4;
-    { const char *dbg = getenv("C1_DEBUG"); L.debug = dbg ? atoi(dbg) : 0; }
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     const bool all_long = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&

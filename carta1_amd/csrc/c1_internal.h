@@ -67,7 +67,6 @@ struct C1EncodeLaunch {
   uint8_t *cand;     // frames*channels*kCandBytes: per-candidate totals and results
   uint32_t *work_list;   // frames*channels*7 entries (unit<<3 | candidate)
   uint32_t *work_count;
-  int debug;         // ablation switches for profiling builds (C1_DEBUG); 0 in normal use
   float *bands;      // optional tap (may be null)
   uint8_t *units;    // frames*channels*212   (may be null for stage taps)
 };
