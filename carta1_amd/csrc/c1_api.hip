@@ -236,6 +236,7 @@ struct c1_ctx {
   float *d_bands[2] = {nullptr, nullptr};
   double *d_feat[2] = {nullptr, nullptr};
   uint8_t *d_modes[2] = {nullptr, nullptr};
+  uint32_t *d_lists[2] = {nullptr, nullptr};
   int64_t chunk_frames = 0;
   bool pipeline = true;
   hipStream_t s_ana = nullptr, s_rest = nullptr;  // internal streams of the two pipeline halves
@@ -273,7 +274,8 @@ void free_workspace(c1_ctx *ctx) {
     if (ctx->d_bands[p]) (void)hipFree(ctx->d_bands[p]);
     if (ctx->d_feat[p]) (void)hipFree(ctx->d_feat[p]);
     if (ctx->d_modes[p]) (void)hipFree(ctx->d_modes[p]);
-    ctx->d_bands[p] = nullptr; ctx->d_feat[p] = nullptr; ctx->d_modes[p] = nullptr;
+    if (ctx->d_lists[p]) (void)hipFree(ctx->d_lists[p]);
+    ctx->d_bands[p] = nullptr; ctx->d_feat[p] = nullptr; ctx->d_modes[p] = nullptr; ctx->d_lists[p] = nullptr;
   }
   ctx->det_units = 0;
 }
@@ -285,11 +287,13 @@ int ensure_detect_workspace(c1_ctx *ctx, int64_t units) {
     if (ctx->d_bands[p]) (void)hipFree(ctx->d_bands[p]);
     if (ctx->d_feat[p]) (void)hipFree(ctx->d_feat[p]);
     if (ctx->d_modes[p]) (void)hipFree(ctx->d_modes[p]);
-    ctx->d_bands[p] = nullptr; ctx->d_feat[p] = nullptr; ctx->d_modes[p] = nullptr;
+    if (ctx->d_lists[p]) (void)hipFree(ctx->d_lists[p]);
+    ctx->d_bands[p] = nullptr; ctx->d_feat[p] = nullptr; ctx->d_modes[p] = nullptr; ctx->d_lists[p] = nullptr;
     // one extra row of slots in front: frame -1 of the batch (c1_internal.h)
     HIP_TRY(hipMalloc(&ctx->d_bands[p], (size_t)(units + C1_MAX_CHANNELS) * 512 * sizeof(float)));
     HIP_TRY(hipMalloc(&ctx->d_feat[p], (size_t)(units + C1_MAX_CHANNELS) * kFeatureWsDoubles * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_modes[p], (size_t)units));
+    HIP_TRY(hipMalloc(&ctx->d_lists[p], ((size_t)units * 2 + 4) * sizeof(uint32_t)));
   }
   ctx->det_units = units;
   return C1_OK;
@@ -445,7 +449,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       ScopedTiming t(ctx, K_ANALYSIS, sA);
       if (all_long) c1k_launch_analysis_long(L, sA);
       else if (detect) {
-        c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], sA);
+        c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], ctx->d_lists[p], sA);
         if (L.bands) HIP_TRY(hipMemcpyAsync(L.bands, ctx->d_bands[p] + (size_t)channels * 512, (size_t)n * channels * 512 * sizeof(float),
                                             hipMemcpyDeviceToDevice, sA));
       } else c1k_launch_analysis(L, false, sA);

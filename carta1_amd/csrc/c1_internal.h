@@ -86,7 +86,9 @@ void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream);   //
 // transient detection: features (runs) -> decisions (per unit) -> MDCT from the stored bands (per unit).
 // bands_ws: (units + channels) * 512 floats, feat_ws: (units + channels) * kFeatureWsDoubles doubles, modes_ws: units bytes
 constexpr int kFeatureWsDoubles = 20;
-void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, hipStream_t stream);
+// lists_ws: 4 + 2 * units uint32 (two counts, then the all-long and the mixed unit list)
+void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
+                       hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);

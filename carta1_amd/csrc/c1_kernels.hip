@@ -1123,11 +1123,9 @@ __device__ __forceinline__ BandFeatures band_features(const double *s, int nv) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_detect_decide(const double *__restrict__ feat_ws, int channels, int64_t frames,
-                                                        int halo_frames, const C1DevTables *tables, const C1DevEncOpts *opts,
-                                                        uint8_t *__restrict__ modes) {
-  const int64_t unit = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (unit >= frames * channels) return;
+// block modes of one sound unit from the feature sums of its frame and of the previous one (encoder.js:137-143)
+__device__ __forceinline__ int detect_decide_unit(const double *__restrict__ feat_ws, int channels, int64_t unit, int halo_frames,
+                                                       const C1DevTables *tables, const C1DevEncOpts *opts) {
   const int64_t f = unit / channels;
   const double *cur = feat_ws + (unit + channels) * kFeatureDoubles;
   const double *prev = cur - (int64_t)channels * kFeatureDoubles;
@@ -1152,8 +1150,35 @@ __global__ __launch_bounds__(256) void k_detect_decide(const double *__restrict_
     const int mode = (score > threshold) ? (b + 1 > 2 ? b + 1 : 2) : 0;   // encoder.js:143
     mode_byte |= mode << (2 * b);
   }
-  modes[unit] = (uint8_t)mode_byte;
+  return mode_byte;
 }
+
+__global__ __launch_bounds__(256) void k_detect_decide(const double *__restrict__ feat_ws, int channels, int64_t frames,
+                                                        int halo_frames, const C1DevTables *tables, const C1DevEncOpts *opts,
+                                                        uint8_t *__restrict__ modes, uint32_t *__restrict__ lists) {
+  const int64_t unit = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t units = frames * channels;
+  const bool live = unit < units;
+  int mode_byte = 0;
+  if (live) mode_byte = detect_decide_unit(feat_ws, channels, unit, halo_frames, tables, opts);
+  if (live) modes[unit] = (uint8_t)mode_byte;
+  // two work lists for the MDCT stage: all-long units and units with a short band (lists[0], lists[1] = counts,
+  // then `units` entries each); one atomic per wave and list
+  uint32_t *list_long = lists + 4, *list_mixed = lists + 4 + units;
+  const bool is_long = live && mode_byte == 0, is_mixed = live && mode_byte != 0;
+  const uint64_t ml = __ballot(is_long), mm = __ballot(is_mixed);
+  const int lane = threadIdx.x & 63;
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint32_t base_l = 0, base_m = 0;
+  if (lane == 0) {
+    if (ml) base_l = atomicAdd(&lists[0], (uint32_t)__popcll(ml));
+    if (mm) base_m = atomicAdd(&lists[1], (uint32_t)__popcll(mm));
+  }
+  base_l = __shfl(base_l, 0); base_m = __shfl(base_m, 0);
+  if (is_long) list_long[base_l + __popcll(ml & below)] = (uint32_t)unit;
+  if (is_mixed) list_mixed[base_m + __popcll(mm & below)] = (uint32_t)unit;
+}
+
 
 
 struct alignas(16) MdctLds {
@@ -1170,17 +1195,23 @@ struct alignas(16) MdctLds {
   } zz;
 };
 
-// mdctStage + scale factors of one sound unit from the stored band samples; units are independent
+// mdctStage + scale factors of one sound unit from the stored band samples; units are independent.  Two
+// instantiations work through the two lists k_detect_decide wrote: LONG (all three bands long, the common case;
+// lean enough for 4 waves per SIMD) and mixed (at least one short band).
+template <bool LONG>
 __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, const float *__restrict__ bands_ws,
-                                                             const uint8_t *__restrict__ modes) {
+                                                                         const uint8_t *__restrict__ modes,
+                                                                         const uint32_t *__restrict__ lists) {
   __shared__ MdctLds S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  const R4Geometry G4 = r4_geometry(lane0);
-  const SfLong SFL = sf_long_geometry(lane0);
+  const int64_t units = L.frames * L.channels;
+  const uint32_t count = lists[LONG ? 0 : 1];
+  const uint32_t *__restrict__ list = lists + 4 + (LONG ? 0 : units);
+  const R4Geometry G4 = r4_geometry(lane0);          // LONG
+  const SfLong SFL = sf_long_geometry(lane0);        // LONG
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
   const TablesRsrc RT = tables_rsrc(L.tables);
-  const int64_t units = L.frames * L.channels;
   // tails of the previous frame: lane < 24 loads four samples of band lane / 8
   const int tail_band = lane0 >> 3, tail_k = 4 * (lane0 & 7);
   const int tail_src = (tail_band == 0 ? 96 : (tail_band == 1 ? 224 : 480)) + tail_k;
@@ -1188,10 +1219,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   const double wt0 = C1_TABLES(L.tables)->window[tail_k & 31], wt1 = C1_TABLES(L.tables)->window[(tail_k + 1) & 31];
   const double wt2 = C1_TABLES(L.tables)->window[(tail_k + 2) & 31], wt3 = C1_TABLES(L.tables)->window[(tail_k + 3) & 31];
   const double win_hi = C1_TABLES(L.tables)->window[31 - (lane0 & 31)];
-  int64_t unit = blockIdx.x;
-  if (unit >= units) return;
+  uint32_t i = blockIdx.x;
+  if (i >= count) return;
   float4 pre_a, pre_b, pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  int pre_mode;
+  int pre_mode = 0;
   auto fetch = [&](int64_t u) {
     const int64_t slot = u + L.channels;
     const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
@@ -1199,15 +1230,22 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     const bool have_prev = ((L.channels == 2 ? u >> 1 : u) - 1 >= -(int64_t)L.halo_frames);
     pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (have_prev && lane0 < 24) pre_t = *reinterpret_cast<const float4 *>(bands_ws + ((slot - L.channels) << 9) + tail_src);
-    pre_mode = modes[u];
+    if (!LONG) pre_mode = modes[u];
   };
+  int64_t unit = list[i];
+  int64_t unit_next = i + gridDim.x < count ? list[i + gridDim.x] : 0;
   fetch(unit);
-  for (; unit < units; unit += gridDim.x) {
+  for (; i < count; i += gridDim.x) {
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
     const float4 a = pre_a, b = pre_b, t = pre_t;
-    const int mode_byte = __builtin_amdgcn_readfirstlane(pre_mode);
-    if (unit + gridDim.x < units) fetch(unit + gridDim.x);
+    const int mode_byte = LONG ? 0 : __builtin_amdgcn_readfirstlane(pre_mode);
+    const int64_t unit_now = unit;
+    if (i + gridDim.x < count) {
+      unit = unit_next;
+      fetch(unit);
+      if (i + 2 * gridDim.x < count) unit_next = list[i + 2 * gridDim.x];
+    }
     reinterpret_cast<float4 *>(S.band)[lane] = a;
     reinterpret_cast<float4 *>(S.band)[64 + lane] = b;
     if (lane < 24) {
@@ -1220,7 +1258,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     __syncthreads();
     const FrameModes M{mode_byte & 3, (mode_byte >> 2) & 3, (mode_byte >> 4) & 3};
     float *coef = S.a.c.coef;
-    if (mode_byte == 0) {
+    if constexpr (LONG) {
       // ---------------- long blocks (encoder.js:228-258) ----------------
       float *in0 = S.a.i.in0, *in1 = S.a.i.in1, *in2 = S.a.i.in2;
       const float *band_ = S.band;
@@ -1258,25 +1296,27 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     }
     // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
     {
-      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
+      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit_now << 9));
       const float4 *src = reinterpret_cast<const float4 *>(coef);
       dst[lane] = src[lane];
       dst[64 + lane] = src[64 + lane];
     }
-    if (mode_byte == 0) {
+    if constexpr (LONG) {
       sf_long(coef, S.sfi, SFL, T);
       if (lane >= 60) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60) % 3] = 0;   // modes byte (all long) and padding
-    } else if (lane < 52) {
-      const int start = M.mode_of_band(band_of_bfu(lane)) == 0 ? my_long : my_short;
-      const int n = my_size;
-      float mx = 0.0f;
-      for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
-      S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
     } else {
-      S.sfi[lane] = lane == 52 ? (uint8_t)mode_byte : 0;
+      if (lane < 52) {
+        const int start = M.mode_of_band(band_of_bfu(lane)) == 0 ? my_long : my_short;
+        const int n = my_size;
+        float mx = 0.0f;
+        for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
+        S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
+      } else {
+        S.sfi[lane] = lane == 52 ? (uint8_t)mode_byte : 0;
+      }
     }
     __syncthreads();
-    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit_now * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
     __syncthreads();
   }
 }
@@ -2273,12 +2313,17 @@ void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t strea
   (void)detect;
   hipLaunchKernelGGL((k_analysis_fast<false>), grid, block, 0, stream, L);
 }
-void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, hipStream_t stream) {
+void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
+                       hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong, units = L.frames * L.channels;
+  (void)hipMemsetAsync(lists_ws, 0, 4 * sizeof(uint32_t), stream);
   hipLaunchKernelGGL(k_detect_features, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
   hipLaunchKernelGGL(k_detect_decide, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, feat_ws, L.channels, L.frames,
-                     L.halo_frames, L.tables, L.opts, modes_ws);
-  hipLaunchKernelGGL(k_mdct_bands, dim3((unsigned)std::min<int64_t>(units, 256 * 48)), dim3(C1_WAVE), 0, stream, L, bands_ws, modes_ws);
+                     L.halo_frames, L.tables, L.opts, modes_ws, lists_ws);
+  // both list kernels size their grids for the whole batch and stop at the device-side count
+  const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
+  hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+  hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
 }
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
