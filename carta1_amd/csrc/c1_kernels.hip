@@ -376,14 +376,21 @@ __device__ __forceinline__ void r2_butterfly_unit(float2 &e, float2 &o) {
   o = make_float2(a.x - b.x, a.y - b.y);
 }
 
+// pre-twiddle pairs of round A, requested by the caller ahead of the core (before the second QMF stage)
+struct R4Early { double2 t0, t1, t2, t3; };
+__device__ __forceinline__ R4Early r4_early(const R4Geometry &G, TablesRsrc R) {
+  R4Early e;
+  e.t0 = table_pair(R, G.pre_tab[0]); e.t1 = table_pair(R, G.pre_tab[1]);
+  e.t2 = table_pair(R, G.pre_tab[2]); e.t3 = table_pair(R, G.pre_tab[3]);
+  return e;
+}
 // in: 1024 floats (in0 | in1 | in2, zero padded long-block inputs); z: 320 slots; coef: 512 floats (may share
 // memory with `in`: the inputs are dead once round A has read them)
-__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R) {
+__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R, const R4Early &E) {
   float2 x[4];
   // the lane-varying table values of the frame are requested up front: the loads are in flight while round A
   // reads its inputs, instead of one cache round trip in front of every round
-  const double2 t0 = table_pair(R, G.pre_tab[0]), t1 = table_pair(R, G.pre_tab[1]);
-  const double2 t2 = table_pair(R, G.pre_tab[2]), t3 = table_pair(R, G.pre_tab[3]);
+  const double2 t0 = E.t0, t1 = E.t1, t2 = E.t2, t3 = E.t3;
   const double2 wBa = table_pair(R, G.twb), wBb = table_pair(R, G.twb + 64), wBc = table_pair(R, G.twb + 128);
   // ---- round A: pre-twiddle + stages 1, 2 ----
   {
@@ -711,6 +718,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       *reinterpret_cast<double2 *>(&w2[pidx<2>(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
     }
     __syncthreads();
+    R4Early EARLY;
+    if constexpr (ALL_LONG) EARLY = r4_early(G4, RT);          // in flight during the second QMF stage
     {
       double ev[2], od[2];
       if (own_block()) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       }
       __syncthreads();
       float *coef = S.u.m.a.c.coef;
-      mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT);
+      mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT, EARLY);
       __syncthreads();
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
@@ -1285,7 +1294,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
       __syncthreads();
-      mdct_long_r4(in0, S.zz.z, coef, G4, T, RT);
+      mdct_long_r4(in0, S.zz.z, coef, G4, T, RT, r4_early(G4, RT));
       __syncthreads();
     } else {
       const MixGeometry GM = mix_geometry(lane, M);
