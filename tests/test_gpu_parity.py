@@ -409,3 +409,54 @@ def test_internal_chunking_is_invisible():
     finally:
         small.close()
         big.close()
+
+
+def _patchwork(frames, seed):
+    """Signal made of short segments of very different character and level: exercises block switching, every
+    scale-factor range, silence / denormal levels and clipping inside one stream."""
+    rng = np.random.RandomState(seed)
+    out = np.zeros(frames * 512, dtype=np.float32)
+    pos = 0
+    t = np.arange(frames * 512, dtype=np.float64)
+    while pos < len(out):
+        n = int(rng.randint(64, 6000))
+        kind = rng.randint(0, 6)
+        gain = 10.0 ** rng.uniform(-6, 0.6)
+        seg = slice(pos, min(pos + n, len(out)))
+        m = seg.stop - seg.start
+        if kind == 0:
+            x = rng.uniform(-1, 1, m)
+        elif kind == 1:
+            x = np.sin(2 * np.pi * rng.uniform(20, 20000) * t[seg] / 44100 + rng.uniform(0, 6.28))
+        elif kind == 2:
+            x = np.cumsum(rng.uniform(-1, 1, m)) * 0.05
+        elif kind == 3:
+            x = np.zeros(m)
+            x[rng.randint(0, m, max(1, m // 200))] = rng.uniform(-1, 1, max(1, m // 200)) * 8
+        elif kind == 4:
+            x = np.zeros(m)
+        else:
+            x = np.sign(np.sin(2 * np.pi * rng.uniform(50, 4000) * t[seg] / 44100))
+        out[seg] = (gain * x).astype(np.float32)
+        pos += n
+    return out
+
+
+@pytest.mark.parametrize('opts', [{}, {'transientThresholdLow': 0.3}, {'fixedBlockModes': [2, 2, 3], 'allocationBias': 2.0},
+                                  {'fixedBlockModes': [0, 0, 0], 'allocationBias': 0.5}])
+def test_patchwork_stream_against_oracle(ctx, opts):
+    import carta1_amd as c1
+    frames = 6000
+    chs = [_patchwork(frames, 101), _patchwork(frames, 202)]
+    bias = opts.get('allocationBias', 1.0)
+    want, _ = O.encode_stream(chs, fixed_modes=opts.get('fixedBlockModes'), bias=bias,
+                              threshold=opts.get('transientThresholdLow', 1.0))
+    got = ctx.encode(chs, c1.EncoderOptions(opts, biased_table=O.biased_table(bias)))
+    assert first_diff(got, want).size == 0, 'units differ at %s' % first_diff(got, want)
+    modes = want[:, 0] >> 2                      # block-size-mode bits of the header byte
+    if 'fixedBlockModes' not in opts:
+        assert len(np.unique(modes)) > 2         # the stream really switches block modes
+    pcm_want, _ = O.decode_stream(want, 2)
+    pcm_got = ctx.decode(want, 2)
+    for c in range(2):
+        assert np.array_equal(pcm_got[c].view(np.uint32), pcm_want[c].view(np.uint32))
