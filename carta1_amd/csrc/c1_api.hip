@@ -459,7 +459,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       HIP_TRY(hipStreamWaitEvent(sB, ctx->ev_ana[p], 0));
     }
     { ScopedTiming t(ctx, K_ALLOCATE, sB); c1k_launch_allocate(L, sB); }
-    if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, sB); }
+    if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, all_long, sB); }
     if (piped) HIP_TRY(hipEventRecord(ctx->ev_free[p], sB));
   }
   if (piped) {

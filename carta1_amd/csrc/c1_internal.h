@@ -90,7 +90,7 @@ constexpr int kFeatureWsDoubles = 20;
 void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
                        hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
-void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream);
+void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream);
 void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream);

@@ -1688,7 +1688,10 @@ __device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, 
   return h;
 }
 
-__global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L) {
+// ALL_LONG: the caller knows every unit of the batch has modes [0,0,0] (fixed block modes): coefficient order ==
+// slot order, no per-slot position tables
+template <bool ALL_LONG>
+__global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack(C1EncodeLaunch L) {
   __shared__ PackLds lds[kPackWaves];
   __shared__ double norm_s[64 * 16];        // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
   TablesPtr T = C1_TABLES(L.tables);
@@ -1703,8 +1706,8 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L)
     const int p = 8 * lane + m;
     slot_b[m] = bfu_of_slot(p);
     slot_j[m] = p - kBfuFirst[slot_b[m]];
-    at_long[m] = kStartLong[slot_b[m]] + slot_j[m];
-    at_short[m] = kStartShort[slot_b[m]] + slot_j[m];
+    at_long[m] = ALL_LONG ? 0 : kStartLong[slot_b[m]] + slot_j[m];
+    at_short[m] = ALL_LONG ? 0 : kStartShort[slot_b[m]] + slot_j[m];
   }
   const int my_size = lane < 52 ? kSpecs[lane] : 0;
   const int my_long = lane < 52 ? kStartLong[lane] : 0, my_short = lane < 52 ? kStartShort[lane] : 0;
@@ -1714,7 +1717,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L)
   auto load_coefs = [&](int64_t unit, uint32_t modes_dword, float (&x)[8]) {
     const float *coefs = L.coefs + (unit << 9);
     const int modes = (int)(modes_dword & 0xff);
-    if (modes == 0) {   // all long: coefficient order == slot order
+    if (ALL_LONG || modes == 0) {   // all long: coefficient order == slot order
       const float4 a = reinterpret_cast<const float4 *>(coefs)[2 * lane], c = reinterpret_cast<const float4 *>(coefs)[2 * lane + 1];
       x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
     } else {
@@ -1742,7 +1745,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves) void k_pack(C1EncodeLaunch L)
     const bool fallback = (a7 >> 27) & 1;
     const int amount = (int)(a7 >> 28) & 7;
     const int n = bfu_amount(amount);
-    const int modes = (int)(__shfl(h0.sd_q, 13) & 0xff);
+    const int modes = ALL_LONG ? 0 : (int)(__shfl(h0.sd_q, 13) & 0xff);
     const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
     if (lane < 56) S.words[lane] = 0;
     int wl = 0, sf = 0;
@@ -2346,8 +2349,10 @@ void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest_blocks), dim3(C1_WAVE), 0, stream, L);
   hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, L);
 }
-void c1k_launch_pack(const C1EncodeLaunch &L, hipStream_t stream) {
-  hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), dim3(C1_WAVE * kPackWaves), 0, stream, L);
+void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream) {
+  const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
+  if (all_long) hipLaunchKernelGGL((k_pack<true>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_pack<false>), grid, block, 0, stream, L);
 }
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesDecode - 1) / kRunFramesDecode;
