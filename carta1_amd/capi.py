@@ -63,6 +63,8 @@ SIGNATURES = {
     'c1_generate_device': (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int64, C.c_void_p]),
     'c1_pcm_from_int_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     'c1_pcm_to_int16_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p]),
+    'c1_host_alloc': (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    'c1_host_free': (C.c_int, [C.c_void_p]),
     'c1_table_fast_paths': (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'c1_aea_header': (C.c_int, [C.c_char_p, C.c_uint32, C.c_int, C.c_void_p]),
     'c1_encode_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,

@@ -108,26 +108,39 @@ class Context:
         return ms.value, n.value
 
     # ---- host-resident batches ------------------------------------------------------------------
-    def encode(self, channels, options=None, halo_frames=0):
+    def encode(self, channels, options=None, halo_frames=0, out=None):
         """channels: list of 1 or 2 float32 arrays, each (halo_frames + frames) * 512 samples.
-        Returns uint8 [frames * nch, 212], units interleaved L,R."""
+        Returns uint8 [frames * nch, 212], units interleaved L,R.  `out`: optional preallocated result (when it
+        and the channels come from pinned_empty() the batch is streamed over PCIe in overlapping chunks)."""
         opts = (options or EncoderOptions()).to_c()
         chans = [np.ascontiguousarray(c, dtype=np.float32) for c in channels]
         n = len(chans[0])
         if any(len(c) != n for c in chans) or n % 512:
             raise ValueError('channels must have equal length, a multiple of 512')
         frames = n // 512 - halo_frames
-        units = np.zeros((max(frames, 0) * len(chans), 212), dtype=np.uint8)
+        if out is None:
+            units = np.zeros((max(frames, 0) * len(chans), 212), dtype=np.uint8)
+        else:
+            units = out
+            if units.dtype != np.uint8 or not units.flags['C_CONTIGUOUS'] or units.size != max(frames, 0) * len(chans) * 212:
+                raise ValueError('out must be a contiguous uint8 array of frames * channels * 212 bytes')
+            units = units.reshape(-1, 212)
         ptrs = capi.ptr_array([c.ctypes.data + halo_frames * 512 * 4 for c in chans])
         capi.check(capi.load().c1_encode_batch(self._h, ptrs, len(chans), frames, halo_frames, C.byref(opts),
                                                units.ctypes.data))
         return units
 
-    def decode(self, units, channels, halo_units=0):
-        """units: uint8 [(halo_units + frames) * channels, 212].  Returns a list of float32 arrays."""
+    def decode(self, units, channels, halo_units=0, out=None):
+        """units: uint8 [(halo_units + frames) * channels, 212].  Returns a list of float32 arrays (`out`: optional
+        preallocated list of them, see encode())."""
         u = np.ascontiguousarray(units, dtype=np.uint8).reshape(-1, 212)
         frames = u.shape[0] // channels - halo_units
-        outs = [np.zeros(max(frames, 0) * 512, dtype=np.float32) for _ in range(channels)]
+        if out is None:
+            outs = [np.zeros(max(frames, 0) * 512, dtype=np.float32) for _ in range(channels)]
+        else:
+            outs = list(out)
+            if len(outs) != channels or any(o.dtype != np.float32 or not o.flags['C_CONTIGUOUS'] or o.size != max(frames, 0) * 512 for o in outs):
+                raise ValueError('out must be one contiguous float32 array of frames * 512 samples per channel')
         ptrs = capi.ptr_array([o.ctypes.data for o in outs])
         capi.check(capi.load().c1_decode_batch(self._h, u.ctypes.data + halo_units * channels * 212, channels,
                                                frames, halo_units, ptrs))
@@ -227,6 +240,20 @@ def parse_aea_header(header):
     return {'title': bytes(header[AEA_TITLE_OFFSET:AEA_TITLE_OFFSET + n]).decode('utf-8', 'replace'),
             'frameCount': struct.unpack_from('<I', header, AEA_FRAME_COUNT_OFFSET)[0],
             'channelCount': header[AEA_CHANNEL_COUNT_OFFSET]}
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (c1_host_alloc).  Batch calls whose host buffers all live in such
+    arrays stream the batch over PCIe in overlapping chunks (include/carta1_hip.h).  Freed with the array."""
+    import weakref
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    ptr = C.c_void_p()
+    capi.check(capi.load().c1_host_alloc(max(1, n * dtype.itemsize), C.byref(ptr)))
+    buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+    weakref.finalize(buf, capi.load().c1_host_free, ptr)
+    return arr
 
 
 _default_ctx = None

@@ -250,6 +250,11 @@ struct c1_ctx {
   // scratch for host-resident calls
   void *d_io = nullptr;
   size_t d_io_bytes = 0;
+  // streamed host path (pinned buffers): copy streams, two chunk-sized staging sets and their events
+  hipStream_t s_up = nullptr, s_down = nullptr;
+  void *d_ring = nullptr;
+  size_t d_ring_bytes = 0;
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -628,6 +633,14 @@ int c1_ctx_destroy(c1_ctx *ctx) {
     if (ctx->ev_end[p]) (void)hipEventDestroy(ctx->ev_end[p]);
   }
   if (ctx->d_io) hipFree(ctx->d_io);
+  if (ctx->d_ring) (void)hipFree(ctx->d_ring);
+  if (ctx->s_up) (void)hipStreamDestroy(ctx->s_up);
+  if (ctx->s_down) (void)hipStreamDestroy(ctx->s_down);
+  for (int p = 0; p < 2; p++) {
+    if (ctx->ev_up[p]) (void)hipEventDestroy(ctx->ev_up[p]);
+    if (ctx->ev_run[p]) (void)hipEventDestroy(ctx->ev_run[p]);
+    if (ctx->ev_down[p]) (void)hipEventDestroy(ctx->ev_down[p]);
+  }
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return C1_OK;
@@ -682,6 +695,149 @@ int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, nullptr, bands, coefs, side, alloc);
 }
 
+// ---- streamed host path --------------------------------------------------------------------------------------
+namespace {
+constexpr int64_t kStreamChunkFrames = 32768;   // frames per channel per chunk of the streamed host path
+
+bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+int ensure_ring(c1_ctx *ctx, size_t bytes) {
+  if (!ctx->s_up) {
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
+    for (int p = 0; p < 2; p++) {
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[p], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_run[p], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_down[p], hipEventDisableTiming));
+    }
+  }
+  if (bytes <= ctx->d_ring_bytes) return C1_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  if (ctx->d_ring) (void)hipFree(ctx->d_ring);
+  ctx->d_ring = nullptr; ctx->d_ring_bytes = 0;
+  HIP_TRY(hipMalloc(&ctx->d_ring, bytes));
+  ctx->d_ring_bytes = bytes;
+  return C1_OK;
+}
+
+// upload of chunk i+1 | kernels of chunk i | download of chunk i-1, two staging sets.  The download of chunk i-1 is
+// queued after the upload and the kernels of chunk i, so a download into pageable memory (which blocks the host
+// until it is done) still leaves the other two stages of the next chunk in flight.
+int encode_batch_streamed(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                          const c1_encode_options *opts, uint8_t *units) {
+  const int64_t chunk = kStreamChunkFrames;
+  const size_t in_bytes = (size_t)(chunk + 2) * 512 * sizeof(float);            // per channel, with the 2-frame halo
+  const size_t out_bytes = ((size_t)chunk * channels * C1_UNIT_BYTES + 255) & ~(size_t)255;
+  const size_t set_bytes = in_bytes * channels + out_bytes;
+  int rc = ensure_ring(ctx, 2 * set_bytes);
+  if (rc) return rc;
+  auto download = [&](int64_t index) -> int {
+    const int p = (int)(index & 1);
+    const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
+    const uint8_t *d_units = reinterpret_cast<const uint8_t *>((char *)ctx->d_ring + (size_t)p * set_bytes + in_bytes * channels);
+    HIP_TRY(hipStreamWaitEvent(ctx->s_down, ctx->ev_run[p], 0));
+    HIP_TRY(hipMemcpyAsync(units + (size_t)f0 * channels * C1_UNIT_BYTES, d_units, (size_t)n * channels * C1_UNIT_BYTES,
+                           hipMemcpyDeviceToHost, ctx->s_down));
+    HIP_TRY(hipEventRecord(ctx->ev_down[p], ctx->s_down));
+    return C1_OK;
+  };
+  int64_t index = 0;
+  for (int64_t f0 = 0; f0 < frames; f0 += chunk, ++index) {
+    const int p = (int)(index & 1);
+    const int64_t n = std::min(chunk, frames - f0);
+    const int h = (int)std::min<int64_t>(2, f0 + halo_frames);
+    char *set = (char *)ctx->d_ring + (size_t)p * set_bytes;
+    if (index >= 2) {                                           // staging set p is free again
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_run[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_down[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_down[p], 0));
+    }
+    const float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+    for (int c = 0; c < channels; c++) {
+      float *d = reinterpret_cast<float *>(set + in_bytes * c);
+      HIP_TRY(hipMemcpyAsync(d, pcm[c] + (f0 - h) * 512, (size_t)(n + h) * 512 * sizeof(float), hipMemcpyHostToDevice, ctx->s_up));
+      dptr[c] = d + (size_t)h * 512;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_up[p], ctx->s_up));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[p], 0));
+    uint8_t *d_units = reinterpret_cast<uint8_t *>(set + in_bytes * channels);
+    if ((rc = c1_encode_device(ctx, dptr, channels, n, h, opts, d_units))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_run[p], ctx->stream));
+    if (index >= 1 && (rc = download(index - 1))) return rc;
+  }
+  if ((rc = download(index - 1))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->s_down));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int decode_batch_streamed(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int halo_units, float *const *pcm) {
+  const int64_t chunk = kStreamChunkFrames;
+  const size_t in_bytes = ((size_t)(chunk + 1) * channels * C1_UNIT_BYTES + 255) & ~(size_t)255;
+  const size_t out_bytes = (size_t)chunk * 512 * sizeof(float);                // per channel
+  const size_t set_bytes = in_bytes + out_bytes * channels;
+  int rc = ensure_ring(ctx, 2 * set_bytes);
+  if (rc) return rc;
+  auto download = [&](int64_t index) -> int {
+    const int p = (int)(index & 1);
+    const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
+    char *set = (char *)ctx->d_ring + (size_t)p * set_bytes;
+    HIP_TRY(hipStreamWaitEvent(ctx->s_down, ctx->ev_run[p], 0));
+    for (int c = 0; c < channels; c++)
+      HIP_TRY(hipMemcpyAsync(pcm[c] + f0 * 512, set + in_bytes + out_bytes * c, (size_t)n * 512 * sizeof(float), hipMemcpyDeviceToHost, ctx->s_down));
+    HIP_TRY(hipEventRecord(ctx->ev_down[p], ctx->s_down));
+    return C1_OK;
+  };
+  int64_t index = 0;
+  for (int64_t f0 = 0; f0 < frames; f0 += chunk, ++index) {
+    const int p = (int)(index & 1);
+    const int64_t n = std::min(chunk, frames - f0);
+    const int h = (int)std::min<int64_t>(1, f0 + halo_units);
+    char *set = (char *)ctx->d_ring + (size_t)p * set_bytes;
+    if (index >= 2) {
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_run[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_down[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_down[p], 0));
+    }
+    const size_t hb = (size_t)h * channels * C1_UNIT_BYTES;
+    HIP_TRY(hipMemcpyAsync(set, units + (size_t)f0 * channels * C1_UNIT_BYTES - hb, (size_t)n * channels * C1_UNIT_BYTES + hb,
+                           hipMemcpyHostToDevice, ctx->s_up));
+    HIP_TRY(hipEventRecord(ctx->ev_up[p], ctx->s_up));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[p], 0));
+    float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+    for (int c = 0; c < channels; c++) dptr[c] = reinterpret_cast<float *>(set + in_bytes + out_bytes * c);
+    if ((rc = c1_decode_device(ctx, (const uint8_t *)set + hb, channels, n, h, dptr))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_run[p], ctx->stream));
+    if (index >= 1 && (rc = download(index - 1))) return rc;
+  }
+  if ((rc = download(index - 1))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->s_down));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+}  // namespace
+
+int c1_host_alloc(size_t bytes, void **out) {
+  if (!out) return fail(C1_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return C1_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); return fail(C1_ERR_NO_DEVICE, "no HIP device: page-locked memory needs the HIP runtime"); }
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return C1_OK;
+}
+
+int c1_host_free(void *p) {
+  if (!p) return C1_OK;
+  HIP_TRY(hipHostFree(p));
+  return C1_OK;
+}
+
 int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                     const c1_encode_options *opts, uint8_t *units) {
   int rc = ctx_bind(ctx);
@@ -690,6 +846,12 @@ int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t 
   if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
   if (frames == 0) return C1_OK;
   if (!pcm || !units) return fail(C1_ERR_ARG, "pcm or units is NULL");
+  {
+    // the PCM is 95 % of the traffic: page-locked PCM is what makes streaming worthwhile
+    bool pinned = frames > kStreamChunkFrames;
+    for (int c = 0; c < channels && pinned; c++) pinned = pcm[c] && is_pinned_host(pcm[c]);
+    if (pinned) return encode_batch_streamed(ctx, pcm, channels, frames, halo_frames, opts, units);
+  }
   const size_t ch_bytes = (size_t)(frames + halo_frames) * 512 * sizeof(float);
   const size_t unit_bytes = (size_t)frames * channels * C1_UNIT_BYTES;
   const size_t unit_off = (ch_bytes * channels + 255) & ~(size_t)255;
@@ -744,6 +906,11 @@ int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fra
   if (frames < 0 || halo_units < 0 || halo_units > 1) return fail(C1_ERR_ARG, "bad frames / halo_units");
   if (frames == 0) return C1_OK;
   if (!units || !pcm) return fail(C1_ERR_ARG, "units or pcm is NULL");
+  {
+    bool pinned = frames > kStreamChunkFrames;
+    for (int c = 0; c < channels && pinned; c++) pinned = pcm[c] && is_pinned_host(pcm[c]);
+    if (pinned) return decode_batch_streamed(ctx, units, channels, frames, halo_units, pcm);
+  }
   const size_t halo_bytes = (size_t)halo_units * channels * C1_UNIT_BYTES;   // multiple of 4
   const size_t unit_bytes = (size_t)frames * channels * C1_UNIT_BYTES + halo_bytes;
   const size_t pcm_off = (unit_bytes + 255) & ~(size_t)255;

@@ -93,19 +93,53 @@ bool get_channels(napi_env env, napi_value arr, std::vector<float *> *ptrs, size
   return true;
 }
 
+// ArrayBuffer of `bytes` bytes.  Large PCM buffers come from page-locked memory (c1_host_alloc) so that the batch calls
+// stream them over PCIe in overlapping chunks; they are released by the garbage collector (c1_host_free).
+constexpr size_t kPinnedThreshold = (size_t)32768 * 512 * 4;   // one streaming chunk of one channel
+void free_pinned(napi_env, void *data, void *) { c1_host_free(data); }
+bool make_buffer(napi_env env, size_t bytes, bool pinned, void **data, napi_value *ab) {
+  if (pinned && bytes > 0) {
+    void *p = nullptr;
+    if (c1_host_alloc(bytes, &p) == C1_OK && p) {
+      if (napi_create_external_arraybuffer(env, p, bytes, free_pinned, nullptr, ab) == napi_ok) { *data = p; return true; }
+      c1_host_free(p);
+    }
+  }
+  return napi_create_arraybuffer(env, bytes, data, ab) == napi_ok;
+}
 napi_value make_u8(napi_env env, size_t n, uint8_t **data) {
   napi_value ab, ta;
   void *p;
-  if (napi_create_arraybuffer(env, n, &p, &ab) != napi_ok || napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;
+  if (!make_buffer(env, n, false, &p, &ab) || napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;
   *data = static_cast<uint8_t *>(p);
   return ta;
 }
 napi_value make_f32(napi_env env, size_t n, float **data) {
   napi_value ab, ta;
   void *p;
-  if (napi_create_arraybuffer(env, n * 4, &p, &ab) != napi_ok || napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) return nullptr;
+  if (!make_buffer(env, n * 4, n * 4 > kPinnedThreshold, &p, &ab) || napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) return nullptr;
   *data = static_cast<float *>(p);
   return ta;
+}
+
+// allocPinned(bytes) -> ArrayBuffer in page-locked memory: PCM placed there is uploaded at the pinned PCIe rate
+napi_value AllocPinned(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  int64_t bytes = 0;
+  NAPI_OK(napi_get_value_int64(env, argv[0], &bytes));
+  if (bytes < 0) { napi_throw_range_error(env, nullptr, "bytes must be >= 0"); return nullptr; }
+  void *p = nullptr;
+  const int rc = c1_host_alloc((size_t)bytes, &p);
+  if (rc) return throw_c1(env, rc);
+  napi_value ab;
+  if (bytes == 0) { NAPI_OK(napi_create_arraybuffer(env, 0, &p, &ab)); return ab; }
+  if (napi_create_external_arraybuffer(env, p, (size_t)bytes, free_pinned, nullptr, &ab) != napi_ok) {
+    c1_host_free(p);
+    napi_throw_error(env, nullptr, "allocation failed");
+    return nullptr;
+  }
+  return ab;
 }
 
 // ---- library ---------------------------------------------------------------------------------------
@@ -418,6 +452,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"getDefaultTables", nullptr, GetDefaultTables, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"setTables", nullptr, SetTables, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"ctxCreate", nullptr, CtxCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"allocPinned", nullptr, AllocPinned, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"encodeBatch", nullptr, EncodeBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"decodeBatch", nullptr, DecodeBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"encodeBatchAsync", nullptr, EncodeBatchAsync, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -11,4 +11,4 @@ export { BufferPool } from './core/buffers.js'
 export { EncoderOptions } from './core/options.js'
 export { pipe } from './utils.js'
 export { WORD_LENGTH_BITS, SPECS_PER_BFU, SCALE_FACTORS, BFU_START_LONG } from './core/constants.js'
-export { deviceCount } from './native.js'
+export { deviceCount, allocPinnedFloat32Array } from './native.js'

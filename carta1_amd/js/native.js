@@ -29,3 +29,9 @@ export function context(device = 0) {
 export function deviceCount() {
   return native().deviceCount()
 }
+
+// Float32Array in page-locked host memory: PCM placed there is uploaded at the pinned PCIe rate and large batches
+// are streamed (upload, kernels and download of consecutive chunks overlap).  Garbage collected like any array.
+export function allocPinnedFloat32Array(length) {
+  return new Float32Array(native().allocPinned(length * 4))
+}

@@ -117,6 +117,17 @@ async function main() {
     const frames = c1.AudioProcessor.frameBufferToFrames([white(11, 700), white(12, 700)])
     const fieldsList = await c1.AudioProcessor.collectFrames(c1.AudioProcessor.encodeStream(frames, { channelCount: 2 }))
     ok(fieldsList.length === 4 && hex(await c1.AudioProcessor.createAeaBytes(fieldsList, { title: 'encoded by carta1', channelCount: 2 })) === hex(img), 'AudioProcessor.encodeStream == encodeAeaPcm')
+    // page-locked PCM: a batch of more than one streaming chunk (32768 frames) must give the same bytes
+    {
+      const nf = 40000, plain = white(21, nf * 512)
+      const pinned = c1.allocPinnedFloat32Array(nf * 512)
+      pinned.set(plain)
+      const a = await c1.encodeAeaPcm([plain], { fixedBlockModes: [0, 0, 0] })
+      const b = await c1.encodeAeaPcm([pinned], { fixedBlockModes: [0, 0, 0] })
+      ok(Buffer.from(a.buffer, a.byteOffset, a.length).equals(Buffer.from(b.buffer, b.byteOffset, b.length)), 'encodeAeaPcm from page-locked PCM (streamed) == plain')
+      const back = await c1.decodeAeaPcm(b)
+      ok(back.length === 1 && back[0].length === nf * 512, 'decodeAeaPcm of 40000 frames (page-locked output buffers)')
+    }
   }
   console.log(failed ? `${failed} FAILED` : 'ALL OK')
   process.exit(failed ? 1 : 0)

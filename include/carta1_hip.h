@@ -118,6 +118,13 @@ int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t
 int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
                     int halo_frames, const c1_encode_options *opts, uint8_t *units);
 
+/* Page-locked host memory for the *_batch calls.  When the PCM buffers handed to c1_encode_batch /
+ * c1_decode_batch lie in memory from c1_host_alloc (or otherwise registered with HIP), the call streams the
+ * batch in chunks: upload of chunk i+1, kernels of chunk i and download of chunk i-1 overlap, and the PCIe link
+ * runs at its pinned-memory rate.  With pageable buffers the same calls copy, compute, copy. */
+int c1_host_alloc(size_t bytes, void **out);
+int c1_host_free(void *p);
+
 /* ---- decode: replaces the decode() frame closure body, decoder.js:408-411
  *      (dequantizationStage :52-98, imdctStage :116-330, qmfSynthesisStage :349-389)
  *      plus deserializeFrame (serialization.js:111-176), batched ----------------------------- */

@@ -165,3 +165,16 @@ def test_table_dependent_shortcuts_are_verified_for_the_default_tables():
     finally:
         lib.c1_set_tables(None)
     assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (1, 1)
+
+
+def test_page_locked_allocation_needs_a_device():
+    """c1_host_alloc is HIP host memory: without a device it fails loudly like every other entry point."""
+    from carta1_amd import capi
+    lib = capi.load()
+    n = C.c_int(0)
+    if lib.c1_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip('a HIP device is present')
+    p = C.c_void_p()
+    assert lib.c1_host_alloc(1 << 20, C.byref(p)) != 0 and not p.value
+    assert b'no HIP device' in lib.c1_last_error()
+    assert lib.c1_host_free(None) == 0

@@ -460,3 +460,29 @@ def test_patchwork_stream_against_oracle(ctx, opts):
     pcm_got = ctx.decode(want, 2)
     for c in range(2):
         assert np.array_equal(pcm_got[c].view(np.uint32), pcm_want[c].view(np.uint32))
+
+
+def test_streamed_pinned_host_path_equals_plain_batch(ctx):
+    """c1_encode_batch / c1_decode_batch with every host buffer in page-locked memory stream the batch in overlapping
+    chunks of 32768 frames; the bytes must not depend on that (chunk seams carry the PCM halo / the previous unit)."""
+    import carta1_amd as c1
+    frames = 32768 * 2 + 777
+    chs = [O.gen_pinkT(51, (frames + 2) * 512), O.gen_pinkT(52, (frames + 2) * 512)]
+    for opts, halo in (({}, 2), ({'fixedBlockModes': [0, 0, 0]}, 1), ({'fixedBlockModes': [2, 2, 3]}, 0)):
+        src = [c[(2 - halo) * 512:] for c in chs]
+        want = ctx.encode(src, c1.EncoderOptions(opts), halo_frames=halo)
+        pin = [c1.pinned_empty(len(s), np.float32) for s in src]
+        for a, b in zip(pin, src):
+            a[:] = b
+        out = c1.pinned_empty((frames * 2, 212), np.uint8)
+        got = ctx.encode(pin, c1.EncoderOptions(opts), halo_frames=halo, out=out)
+        assert np.array_equal(got, want), opts
+    # decode with one unit of history in front
+    units = want
+    ref = ctx.decode(units, 2, halo_units=1)
+    pu = c1.pinned_empty(units.shape, np.uint8)
+    pu[:] = units
+    po = [c1.pinned_empty((frames - 1) * 512, np.float32) for _ in range(2)]
+    got = ctx.decode(pu, 2, halo_units=1, out=po)
+    for c in range(2):
+        assert np.array_equal(got[c].view(np.uint32), ref[c].view(np.uint32))
