@@ -66,6 +66,8 @@ SIGNATURES = {
     'c1_host_alloc': (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     'c1_host_free': (C.c_int, [C.c_void_p]),
     'c1_table_fast_paths': (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'c1_encode_wav_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(EncodeOptions), C.c_void_p]),
+    'c1_decode_wav16_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     'c1_aea_header': (C.c_int, [C.c_char_p, C.c_uint32, C.c_int, C.c_void_p]),
     'c1_encode_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                           C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -159,6 +159,28 @@ class Context:
     def generate_device(self, signal, seed, frames, pcm_ptr):
         capi.check(capi.load().c1_generate_device(self._h, signal, seed, frames, C.c_void_p(pcm_ptr)))
 
+    def encode_wav(self, raw, bits, channels, options=None, out=None):
+        """raw: the body of a WAV file (interleaved little-endian integer PCM, bits = 16, 24 or 32) as bytes or a
+        uint8 array.  Returns uint8 [ceil(samples / 512) * channels, 212].  Conversion happens on the device."""
+        opts = (options or EncoderOptions()).to_c()
+        buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        bps = bits // 8
+        if buf.size % (bps * channels):
+            raise ValueError('raw length is not a whole number of %d-bit %d-channel samples' % (bits, channels))
+        samples = buf.size // (bps * channels)
+        frames = (samples + 511) // 512
+        units = out if out is not None else np.zeros((frames * channels, 212), dtype=np.uint8)
+        capi.check(capi.load().c1_encode_wav_batch(self._h, buf.ctypes.data, bits, channels, samples, C.byref(opts), units.ctypes.data))
+        return units.reshape(-1, 212)
+
+    def decode_wav16(self, units, channels, out=None):
+        """units: uint8 [frames * channels, 212].  Returns int16 [frames * 512, channels] (a 16-bit WAV body)."""
+        u = np.ascontiguousarray(units, dtype=np.uint8).reshape(-1, 212)
+        frames = u.shape[0] // channels
+        pcm = out if out is not None else np.zeros((frames * 512, channels), dtype=np.int16)
+        capi.check(capi.load().c1_decode_wav16_batch(self._h, u.ctypes.data, channels, frames, pcm.ctypes.data))
+        return pcm
+
     def pcm_from_int_device(self, src_ptr, bits, channels, samples, pcm_ptrs):
         capi.check(capi.load().c1_pcm_from_int_device(self._h, C.c_void_p(src_ptr), bits, channels, samples, capi.ptr_array(pcm_ptrs)))
 

@@ -928,6 +928,122 @@ int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fra
   return C1_OK;
 }
 
+// ---- WAV body <-> units in one host call (streamed) -----------------------------------------------------------------
+int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int channels, int64_t samples_per_channel,
+                        const c1_encode_options *opts, uint8_t *units) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (bits != 16 && bits != 24 && bits != 32) return fail(C1_ERR_ARG, "bits must be 16, 24 or 32, got %d", bits);
+  if (samples_per_channel < 0) return fail(C1_ERR_ARG, "samples_per_channel must be >= 0");
+  if (samples_per_channel == 0) return C1_OK;
+  if (!interleaved || !units) return fail(C1_ERR_ARG, "interleaved or units is NULL");
+  const int64_t frames = (samples_per_channel + 511) / 512, chunk = kStreamChunkFrames;
+  const size_t bps = (size_t)bits / 8, frame_raw = 512 * (size_t)channels * bps;
+  const size_t raw_bytes = ((size_t)(chunk + 2) * frame_raw + 255) & ~(size_t)255;
+  const size_t pcm_bytes = (size_t)(chunk + 2) * 512 * sizeof(float);          // per channel
+  const size_t out_bytes = ((size_t)chunk * channels * C1_UNIT_BYTES + 255) & ~(size_t)255;
+  const size_t set_bytes = raw_bytes + pcm_bytes * channels + out_bytes;
+  if ((rc = ensure_ring(ctx, 2 * set_bytes))) return rc;
+  const uint8_t *src = static_cast<const uint8_t *>(interleaved);
+  auto download = [&](int64_t index) -> int {
+    const int p = (int)(index & 1);
+    const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
+    const uint8_t *d_units = reinterpret_cast<const uint8_t *>((char *)ctx->d_ring + (size_t)p * set_bytes + raw_bytes + pcm_bytes * channels);
+    HIP_TRY(hipStreamWaitEvent(ctx->s_down, ctx->ev_run[p], 0));
+    HIP_TRY(hipMemcpyAsync(units + (size_t)f0 * channels * C1_UNIT_BYTES, d_units, (size_t)n * channels * C1_UNIT_BYTES,
+                           hipMemcpyDeviceToHost, ctx->s_down));
+    HIP_TRY(hipEventRecord(ctx->ev_down[p], ctx->s_down));
+    return C1_OK;
+  };
+  int64_t index = 0;
+  for (int64_t f0 = 0; f0 < frames; f0 += chunk, ++index) {
+    const int p = (int)(index & 1);
+    const int64_t n = std::min(chunk, frames - f0);
+    const int h = (int)std::min<int64_t>(2, f0);                 // frames of PCM history in front of the chunk
+    char *set = (char *)ctx->d_ring + (size_t)p * set_bytes;
+    if (index >= 2) {
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_run[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_down[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_down[p], 0));
+    }
+    const int64_t s0 = (f0 - h) * 512;                                         // first sample (per channel) of the upload
+    const int64_t have = std::min<int64_t>((n + h) * 512, samples_per_channel - s0);
+    HIP_TRY(hipMemcpyAsync(set, src + (size_t)s0 * channels * bps, (size_t)have * channels * bps, hipMemcpyHostToDevice, ctx->s_up));
+    HIP_TRY(hipEventRecord(ctx->ev_up[p], ctx->s_up));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[p], 0));
+    float *dch[C1_MAX_CHANNELS] = {nullptr, nullptr};
+    const float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+    for (int c = 0; c < channels; c++) {
+      dch[c] = reinterpret_cast<float *>(set + raw_bytes + pcm_bytes * c);
+      dptr[c] = dch[c] + (size_t)h * 512;
+      if (have < (n + h) * 512)                                                // zero padding of the last, partial frame
+        HIP_TRY(hipMemsetAsync(dch[c] + have, 0, (size_t)((n + h) * 512 - have) * sizeof(float), ctx->stream));
+    }
+    c1k_launch_pcm_from_int(set, bits, channels, have, dch, ctx->stream);
+    if ((rc = c1_encode_device(ctx, dptr, channels, n, h, opts, reinterpret_cast<uint8_t *>(set + raw_bytes + pcm_bytes * channels)))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_run[p], ctx->stream));
+    if (index >= 1 && (rc = download(index - 1))) return rc;
+  }
+  if ((rc = download(index - 1))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->s_down));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_decode_wav16_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int16_t *interleaved) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
+  if (frames == 0) return C1_OK;
+  if (!units || !interleaved) return fail(C1_ERR_ARG, "units or interleaved is NULL");
+  const int64_t chunk = kStreamChunkFrames;
+  const size_t in_bytes = ((size_t)(chunk + 1) * channels * C1_UNIT_BYTES + 255) & ~(size_t)255;
+  const size_t pcm_bytes = (size_t)chunk * 512 * sizeof(float);                // per channel
+  const size_t out_bytes = (size_t)chunk * 512 * channels * sizeof(int16_t);
+  const size_t set_bytes = in_bytes + pcm_bytes * channels + out_bytes;
+  if ((rc = ensure_ring(ctx, 2 * set_bytes))) return rc;
+  auto download = [&](int64_t index) -> int {
+    const int p = (int)(index & 1);
+    const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
+    char *set = (char *)ctx->d_ring + (size_t)p * set_bytes;
+    HIP_TRY(hipStreamWaitEvent(ctx->s_down, ctx->ev_run[p], 0));
+    HIP_TRY(hipMemcpyAsync(interleaved + (size_t)f0 * 512 * channels, set + in_bytes + pcm_bytes * channels,
+                           (size_t)n * 512 * channels * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->s_down));
+    HIP_TRY(hipEventRecord(ctx->ev_down[p], ctx->s_down));
+    return C1_OK;
+  };
+  int64_t index = 0;
+  for (int64_t f0 = 0; f0 < frames; f0 += chunk, ++index) {
+    const int p = (int)(index & 1);
+    const int64_t n = std::min(chunk, frames - f0);
+    const int h = (int)std::min<int64_t>(1, f0);
+    char *set = (char *)ctx->d_ring + (size_t)p * set_bytes;
+    if (index >= 2) {
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_run[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->s_up, ctx->ev_down[p], 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_down[p], 0));
+    }
+    const size_t hb = (size_t)h * channels * C1_UNIT_BYTES;
+    HIP_TRY(hipMemcpyAsync(set, units + (size_t)f0 * channels * C1_UNIT_BYTES - hb, (size_t)n * channels * C1_UNIT_BYTES + hb,
+                           hipMemcpyHostToDevice, ctx->s_up));
+    HIP_TRY(hipEventRecord(ctx->ev_up[p], ctx->s_up));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[p], 0));
+    float *dptr[C1_MAX_CHANNELS] = {nullptr, nullptr};
+    for (int c = 0; c < channels; c++) dptr[c] = reinterpret_cast<float *>(set + in_bytes + pcm_bytes * c);
+    if ((rc = c1_decode_device(ctx, (const uint8_t *)set + hb, channels, n, h, dptr))) return rc;
+    c1k_launch_pcm_to_int16(dptr, channels, n * 512, reinterpret_cast<int16_t *>(set + in_bytes + pcm_bytes * channels), ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev_run[p], ctx->stream));
+    if (index >= 1 && (rc = download(index - 1))) return rc;
+  }
+  if ((rc = download(index - 1))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->s_down));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
 // ---- stateful streams -------------------------------------------------------------------------------
 struct c1_enc_stream {
   c1_ctx *ctx;

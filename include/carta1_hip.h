@@ -164,6 +164,16 @@ int c1_pcm_from_int_device(c1_ctx *ctx, const void *interleaved, int bits, int c
  * DataView.setInt16 truncation; planar float32 -> little-endian interleaved int16.  Device pointers. */
 int c1_pcm_to_int16_device(c1_ctx *ctx, const float *const *pcm, int channels,
                            int64_t samples_per_channel, int16_t *interleaved);
+/* WAV body <-> sound units in one host call (what the reference's CLI does around the codec: WavReader ->
+ * frameBufferToFrames -> encode, bin/cli.js:367-404, codec/io/processor.js:246-276; and decode -> createWavBlob,
+ * processor.js:349-447).  The integer PCM crosses PCIe (half the bytes of float32 for 16 bit) and is converted on
+ * the device; batches are streamed in chunks, at the pinned rate when the host buffers are page-locked.
+ * samples_per_channel need not be a multiple of 512: the last frame is zero padded as frameBufferToFrames does.
+ * units: ceil(samples_per_channel / 512) * channels * 212 bytes. */
+int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int channels, int64_t samples_per_channel,
+                        const c1_encode_options *opts, uint8_t *units);
+/* decode `frames` frames to 16-bit interleaved PCM: frames * 512 * channels int16 */
+int c1_decode_wav16_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int16_t *interleaved);
 /* AeaFile.createHeader, codec/io/serialization.js:190-211 (host side; the units a batch call returns are
  * already the AEA body: header + units is the whole file).  title is UTF-8, truncated to 255 bytes. */
 int c1_aea_header(const char *title, uint32_t unit_count, int channels, uint8_t out[2048]);

@@ -486,3 +486,27 @@ def test_streamed_pinned_host_path_equals_plain_batch(ctx):
     got = ctx.decode(pu, 2, halo_units=1, out=po)
     for c in range(2):
         assert np.array_equal(got[c].view(np.uint32), ref[c].view(np.uint32))
+
+
+@pytest.mark.parametrize('bits,ch', [(16, 2), (24, 1), (32, 2)])
+def test_wav_body_to_units_and_back_in_one_call(ctx, bits, ch):
+    """c1_encode_wav_batch / c1_decode_wav16_batch == the oracle chain WavReader conversion -> zero padded frames ->
+    encode, and decode -> 16-bit samples; more than one streaming chunk, ragged length, plain and page-locked input."""
+    import carta1_amd as c1
+    samples = 32768 * 512 + 5000 + 333                       # two chunks and a partial last frame
+    rng = np.random.default_rng(bits)
+    bps = bits // 8
+    raw = rng.integers(0, 256, size=samples * ch * bps, dtype=np.uint8)
+    if bits > 16:                                            # keep the level sane: zero the low bytes' influence
+        raw.reshape(-1, bps)[:, -1] = rng.integers(-40, 40, size=samples * ch).astype(np.int8).view(np.uint8)
+    chans = O.pcm_from_int(raw, bits, ch)
+    want, _ = O.encode_stream([O.pad_frames(c) for c in chans])
+    got = ctx.encode_wav(raw, bits, ch)
+    assert np.array_equal(got, want), first_diff(got, want)
+    praw = c1.pinned_empty(raw.shape, np.uint8)
+    praw[:] = raw
+    assert np.array_equal(ctx.encode_wav(praw, bits, ch), want)
+    pcm_want, _ = O.decode_stream(want, ch)
+    back = ctx.decode_wav16(want, ch)
+    assert back.shape == (len(pcm_want[0]), ch)
+    assert np.array_equal(back.reshape(-1), O.pcm_to_int16(pcm_want))

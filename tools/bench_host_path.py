@@ -28,3 +28,13 @@ for rep in range(3):
     print('decode_batch pinned: %.1f ms -> %.2f M frames/s' % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e6))
 assert all(np.array_equal(a, b) for a, b in zip(ppcm, p))
 print('pinned results identical')
+# 16-bit WAV body in, units out (and back): half the PCIe bytes of float32 PCM
+raw16 = c1.pinned_empty((n * 512, 2), np.int16)
+raw16[:] = (np.stack(chs, axis=1) * 30000).astype(np.int16)
+for rep in range(3):
+    t0 = time.perf_counter(); uw = ctx.encode_wav(raw16, 16, 2, opt, out=pout); t1 = time.perf_counter()
+    print('encode_wav_batch int16 pinned: %.1f ms -> %.2f M frames/s' % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e6))
+back16 = c1.pinned_empty((n * 512, 2), np.int16)
+for rep in range(3):
+    t0 = time.perf_counter(); ctx.decode_wav16(pout, 2, out=back16); t1 = time.perf_counter()
+    print('decode_wav16_batch pinned: %.1f ms -> %.2f M frames/s' % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e6))
