@@ -1,4 +1,4 @@
-// c1_internal.h -- shared between the HIP kernels (c1_kernels.hip) and the C-ABI host side
+// c1_internal.h -- shared between the HIP kernels (c1_k_*.hip, c1_device.h) and the C-ABI host side
 // (c1_api.hip).  Not part of the public boundary (that is include/carta1_hip.h).
 #pragma once
 
@@ -80,7 +80,7 @@ struct C1DecodeLaunch {
   float *pcm[C1_MAX_CHANNELS];
 };
 
-// launchers (c1_kernels.hip); all asynchronous on `stream`
+// launchers (one per c1_k_*.hip file); all asynchronous on `stream`
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0]
 // transient detection: features (runs) -> decisions (per unit) -> MDCT from the stored bands (per unit).

@@ -1,0 +1,301 @@
+// c1_k_allocate.hip -- allocateBits (bitallocation.js:74-142): the greedy RDO heaps, one lane per heap
+#include "c1_device.h"
+
+namespace {
+
+// =====================================================================================================
+// bit allocation : allocateBits (bitallocation.js:74-142) as three small kernels
+// =====================================================================================================
+// The reference runs the greedy heap (distributeBitsRDO, :203-281) for all 8 candidate BFU counts and
+// keeps the one with the smallest total distortion (:116-129).  Each candidate is independent, so:
+//   k_alloc_first   one lane per sound unit: the 52-BFU candidate.  It then bounds every other candidate
+//                   from below without running it: a candidate that codes n BFUs pays at least the
+//                   zero-bit distortion of BFUs n..51, summed in the reference's own order (floating-point
+//                   addition is monotone, every term is >= 0, so the bound holds for the rounded sums too).
+//                   A candidate whose bound already exceeds the 52-BFU total can never win the strict `<`
+//                   comparison and is skipped; the others are appended to a work list.
+//   k_alloc_rest    one lane per work-list entry (unit, candidate): the same heap run.
+//   k_alloc_select  one lane per unit: smallest total, smallest count on ties (:116-129), or the
+//                   fallback when no total is finite (:132-139).
+//
+// Heap entry (one 32-bit word, bit 31 clear):  rank(10) | size(5) | sfi(6) | wl(4) | bfu(6).
+// `rank` orders the Float32 priorities biasedSF[sfi]*DISTORTION_DELTA_FACTORS[wl]/WORD_LENGTH_DELTA_BITS[wl]
+// (bitallocation.js:226-231,267-269) exactly: equal priorities have equal rank, so the strict `>` of
+// siftDown (:325-331) -- and with it the tie order -- is reproduced.  With kLow = the 21 payload bits,
+// rank(a) > rank(b)  <=>  a > (b | kLow): one integer compare, no field extraction.  Rank 0 never occurs
+// in a live entry, so zeroed slots and parked entries (below) act as sentinels: no bounds checks in the sift.
+//
+// Heaps live in LDS as heap[slot][lane] (64 dwords per slot: conflict-free, the two children of a node one
+// ds_read2st64 apart).  An entry that leaves the heap is parked, rank cleared, in the slot the shrinking
+// heap frees, so when the loop ends slots [0, initial size) hold every BFU with its final word length.
+constexpr int kHeapSlotsPerLane = 52 + 2;   // + two zero sentinels behind the last slot
+constexpr uint32_t kLow = 0x1FFFFFu;
+constexpr int kCandBytes = kCandidateBytes;  // per unit: 8 totals (double) + 8 x 32-byte results
+
+__device__ __forceinline__ uint32_t heap_entry(uint32_t rank, int size, int s, int wl, int b) {
+  return (rank << 21) | ((uint32_t)size << 16) | ((uint32_t)s << 10) | ((uint32_t)wl << 6) | (uint32_t)b;
+}
+
+// siftDown (bitallocation.js:314-341) for every lane of the wave at once.  `el`,`er` are the already
+// loaded children of `i`; lanes finish at different depths, the loop runs while any lane still moves.
+__device__ __forceinline__ void heap_sift_down(uint32_t *hp, int sentinel, int i, uint32_t v, uint32_t el,
+                                               uint32_t er, bool active) {
+  const uint32_t vmax = v | kLow;
+  for (;;) {
+    const uint32_t m = max(el | kLow, vmax);
+    const bool take_r = er > m;                    // pr > max(pl, pv)
+    const bool take_l = !take_r && el > vmax;      // pl > pv
+    const bool moved = active && (take_r || take_l);
+    if (active) hp[i * 64] = moved ? (take_r ? er : el) : v;   // a lane that stops here drops v into place
+    active = moved;
+    if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+    i = moved ? 2 * i + 1 + (take_r ? 1 : 0) : i;
+    const uint32_t *src = hp + min(2 * i + 1, sentinel) * 64;
+    el = src[0];
+    er = src[64];
+  }
+}
+
+// One greedy heap per lane: candidate with `n` BFUs.  sf = the unit's 52 scale-factor indices (13 dwords).
+// Returns the 52 final word-length indices (4 bits each) and the candidate's total distortion.
+// During the spending loop the three top slots of the heap live in registers (r0 = root, r1/r2 = its
+// children): most steps end at the root (equal priorities do not move, :325-331), so they touch no memory.
+__device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_t (&sf)[13], const C1DevEncOpts *O,
+                                              bool live, uint64_t &res0, uint64_t &res1, uint64_t &res2,
+                                              uint64_t &res3, double &total) {
+  const __attribute__((address_space(4))) uint16_t *rank_t = (const __attribute__((address_space(4))) uint16_t *)O->rank;
+  const __attribute__((address_space(4))) double *biased = (const __attribute__((address_space(4))) double *)O->biased;
+  const bool affine = O->rank_affine != 0;
+  const int ka = O->rank_a, kb = O->rank_b, kc = O->rank_c, koff = O->rank_off;
+  auto rank_of = [&](int s, int wl) -> uint32_t {
+    if (affine) return (uint32_t)(ka * s + (wl == 0 ? kc : -kb * wl - kb) + koff);
+    return rank_t[s * 16 + (wl & 15)];
+  };
+  int remaining = 212 * 8 - 40 - 10 * n;                   // bitallocation.js:97-100
+  int hs = 0;
+  // distributeBitsRDO (:203-281): initial heap = BFUs below n with a non-zero scale factor
+#pragma unroll
+  for (int b = 0; b < 52; b++) {
+    const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+    if (b < n && s != 0 && live) {
+      hp[hs * 64] = heap_entry(rank_of(s, 0), kSpecs[b], s, 0, b);
+      hs++;
+    }
+  }
+  const int hs0 = hs;
+  for (int k = hs; k < kHeapSlotsPerLane; k++) hp[k * 64] = 0u;   // sentinels
+  for (int i = (hs >> 1) - 1; i >= 0; i--) {               // heapify (:238-241); per-lane trip counts
+    const int l = 2 * i + 1;
+    heap_sift_down(hp, 52, i, hp[i * 64], hp[l * 64], hp[(l + 1) * 64], true);
+  }
+  // greedy spending loop (:244-278): the root either takes its next priority or leaves the heap (does not
+  // fit :251-258, or reached the last word length :271-277); then one sift.
+  uint32_t r0 = hp[0], r1 = hp[64], r2 = hp[128];
+  bool run = remaining > 0 && hs > 0;
+  while (__builtin_amdgcn_ballot_w64(run) != 0) {
+    const uint32_t top = r0;
+    const int wl = (top >> 6) & 15, size = (top >> 16) & 31, s = (top >> 10) & 63;
+    const int cost = size << (wl == 0 ? 1 : 0);            // WORD_LENGTH_DELTA_BITS = [2,1,1,...]
+    const bool fits = cost <= remaining;
+    const int nxt = wl + (fits ? 1 : 0);
+    const bool leaves = run && (!fits || nxt >= 15);
+    const uint32_t upd = (top & ~((0x3FFu << 21) | (15u << 6))) | ((uint32_t)nxt << 6);   // same BFU, new word length, rank 0
+    uint32_t v = upd | (rank_of(s, nxt) << 21);
+    if (__builtin_amdgcn_ballot_w64(leaves) != 0) {
+      // the last element replaces the root; the leaver is parked, rank 0, in the slot that frees
+      const int li = hs - 1;
+      const uint32_t deep = hp[(li > 3 ? li : 3) * 64];
+      const uint32_t last = li == 0 ? r0 : (li == 1 ? r1 : (li == 2 ? r2 : deep));
+      if (leaves) {
+        v = last;
+        hs = li;
+        if (li > 2) hp[li * 64] = upd;
+        r0 = li == 0 ? upd : r0; r1 = li == 1 ? upd : r1; r2 = li == 2 ? upd : r2;
+      }
+    }
+    if (run) remaining -= fits ? cost : 0;
+    const bool sift = run && hs > 0;
+    // level 0: root against r1, r2
+    const uint32_t vmax = v | kLow;
+    const bool tr0 = r2 > max(r1 | kLow, vmax);
+    const bool tl0 = !tr0 && r1 > vmax;
+    const bool mv0 = sift && (tr0 || tl0);
+    if (sift) r0 = mv0 ? (tr0 ? r2 : r1) : v;
+    if (__builtin_amdgcn_ballot_w64(mv0) != 0) {
+      // level 1: the chosen child's children are slots 3,4 or 5,6
+      const int i1 = tr0 ? 2 : 1;
+      const uint32_t *src = hp + (2 * i1 + 1) * 64;
+      const uint32_t el = src[0], er = src[64];
+      const bool tr1 = er > max(el | kLow, vmax);
+      const bool tl1 = !tr1 && el > vmax;
+      const bool mv1 = mv0 && (tr1 || tl1);
+      const uint32_t val = mv1 ? (tr1 ? er : el) : v;
+      if (mv0) { if (tr0) r2 = val; else r1 = val; }
+      if (__builtin_amdgcn_ballot_w64(mv1) != 0) {
+        const int i2 = 2 * i1 + 1 + (tr1 ? 1 : 0);
+        const uint32_t *s2 = hp + (2 * i2 + 1) * 64;     // i2 <= 6: children 7..14 always inside the lane's slots
+        heap_sift_down(hp, 52, i2, v, s2[0], s2[64], mv1);
+      }
+    }
+    run = run && remaining > 0 && hs > 0;
+  }
+  hp[0] = r0; hp[64] = r1; hp[128] = r2;
+  // every BFU that ever entered the heap now sits in slots [0, hs0) with its final word length
+  res0 = res1 = res2 = res3 = 0;
+  for (int k = 0; k < hs0; k++) {
+    const uint32_t e = hp[k * 64];
+    const int b = e & 63;
+    const uint64_t v = (uint64_t)((e >> 6) & 15) << ((b & 15) * 4);
+    const int w = b >> 4;
+    res0 |= w == 0 ? v : 0; res1 |= w == 1 ? v : 0; res2 |= w == 2 ? v : 0; res3 |= w == 3 ? v : 0;
+  }
+  // calculateTotalDistortion (:157-190): sequential double sum, index ascending
+  total = 0.0;
+#pragma unroll
+  for (int b = 0; b < 52; b++) {
+    const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+    const uint64_t word = b < 16 ? res0 : (b < 32 ? res1 : (b < 48 ? res2 : res3));
+    const int wl = (int)((word >> ((b & 15) * 4)) & 15);
+    const int size = kSpecs[b];
+    if (b >= n || wl == 0) {
+      // zeroBitDistortions[b] = Float32(biasedSF * 2 * size), 0 when sfi == 0 (:76,87-89)
+      total += s != 0 ? (double)f32(biased[s] * 2.0 * (double)size) : 0.0;
+    } else if (s != 0) {
+      const double ip2 = __hiloint2double((1023 - wl_bits(wl)) << 20, 0);   // INV_POWER_OF_TWO[bits] = 2^-bits
+      total += biased[s] * ip2 * (double)size;
+    }
+  }
+}
+
+__device__ __forceinline__ void load_sfi(const uint8_t *side, int64_t unit, uint32_t (&sf)[13]) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(side + unit * kSideBytes);
+  const uint4 a = src[0], b = src[1], c = src[2];
+  const uint32_t d = reinterpret_cast<const uint32_t *>(src)[12];
+  sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+  sf[8] = c.x; sf[9] = c.y; sf[10] = c.z; sf[11] = c.w; sf[12] = d;
+}
+
+__device__ __forceinline__ void store_candidate(uint8_t *cand, int64_t unit, int c, double total, uint64_t r0,
+                                                uint64_t r1, uint64_t r2, uint64_t r3) {
+  uint8_t *base = cand + unit * kCandBytes;
+  reinterpret_cast<double *>(base)[c] = total;
+  uint64_t *dst = reinterpret_cast<uint64_t *>(base + 64 + c * 32);
+  dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+}
+
+__global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
+  __shared__ uint32_t heap[kHeapSlotsPerLane * 64];
+  const C1DevEncOpts *O = L.opts;
+  const __attribute__((address_space(4))) double *biased = (const __attribute__((address_space(4))) double *)O->biased;
+  const int lane = threadIdx.x;
+  const int64_t units_total = L.frames * L.channels;
+  const int64_t unit = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = unit < units_total;
+  uint32_t sf[13];
+  load_sfi(L.side, live ? unit : 0, sf);
+  uint64_t r0, r1, r2, r3;
+  double total;
+  run_candidate(heap + lane, 52, sf, O, live, r0, r1, r2, r3, total);
+  // lower bounds of the other seven candidates: zero-bit distortion of the BFUs they do not code, each
+  // summed from its first uncoded BFU upwards (one pass, seven running sums)
+  uint32_t survivors = 0;
+  {
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+#pragma unroll
+    for (int b = 20; b < 52; b++) {
+      const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+      const double z = s != 0 ? (double)f32(biased[s] * 2.0 * (double)kSpecs[b]) : 0.0;
+      t0 += z;
+      if (b >= 28) t1 += z;
+      if (b >= 32) t2 += z;
+      if (b >= 36) t3 += z;
+      if (b >= 40) t4 += z;
+      if (b >= 44) t5 += z;
+      if (b >= 48) t6 += z;
+    }
+    // skip only when the bound is strictly above a finite 52-BFU total; NaN / Inf totals prune nothing
+    const bool finite = total < __builtin_huge_val();
+    survivors = (!(finite && t0 > total) ? 1u : 0u) | (!(finite && t1 > total) ? 2u : 0u) |
+                (!(finite && t2 > total) ? 4u : 0u) | (!(finite && t3 > total) ? 8u : 0u) |
+                (!(finite && t4 > total) ? 16u : 0u) | (!(finite && t5 > total) ? 32u : 0u) |
+                (!(finite && t6 > total) ? 64u : 0u);
+  }
+  if (live) {
+    uint8_t *base = L.cand + unit * kCandBytes;
+    double *tot = reinterpret_cast<double *>(base);
+#pragma unroll
+    for (int c = 0; c < 7; c++) tot[c] = __builtin_huge_val();
+    store_candidate(L.cand, unit, 7, total < __builtin_huge_val() ? total : __builtin_huge_val(), r0, r1, r2, r3);
+  }
+  // append the surviving (unit, candidate) pairs to the work list: one atomic per wave
+  const int mine = live ? __popc(survivors) : 0;
+  int scan = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(scan, d);
+    if (lane >= d) scan += o;
+  }
+  const int wave_total = __shfl(scan, 63);
+  uint32_t base_idx = 0;
+  if (lane == 0 && wave_total > 0) base_idx = atomicAdd(L.work_count, (uint32_t)wave_total);
+  base_idx = __shfl(base_idx, 0);
+  if (mine > 0) {
+    uint32_t at = base_idx + (uint32_t)(scan - mine);
+    for (int c = 0; c < 7; c++)
+      if ((survivors >> c) & 1u) L.work_list[at++] = ((uint32_t)(unit - (int64_t)0) << 3) | (uint32_t)c;
+  }
+}
+
+__global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L) {
+  __shared__ uint32_t heap[kHeapSlotsPerLane * 64];
+  const C1DevEncOpts *O = L.opts;
+  const int lane = threadIdx.x;
+  const uint32_t count = *L.work_count;
+  for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
+    const uint32_t idx = base + lane;
+    const bool live = idx < count;
+    const uint32_t item = live ? L.work_list[idx] : 0u;
+    const int64_t unit = item >> 3;
+    const int c = item & 7;
+    uint32_t sf[13];
+    load_sfi(L.side, unit, sf);
+    uint64_t r0, r1, r2, r3;
+    double total;
+    run_candidate(heap + lane, bfu_amount(c), sf, O, live, r0, r1, r2, r3, total);
+    if (live) store_candidate(L.cand, unit, c, total < __builtin_huge_val() ? total : __builtin_huge_val(), r0, r1, r2, r3);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
+  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (unit >= L.frames * L.channels) return;
+  const uint8_t *base = L.cand + unit * kCandBytes;
+  const double *tot = reinterpret_cast<const double *>(base);
+  double best = __builtin_huge_val();
+  int best_c = 8;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {            // ascending count, strict `<`: the smallest count wins ties (:116-129)
+    const double t = tot[c];
+    if (t < best) { best = t; best_c = c; }
+  }
+  uint64_t *dst = reinterpret_cast<uint64_t *>(L.alloc + unit * kAllocBytes);
+  if (best_c < 8) {
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(base + 64 + best_c * 32);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    dst[3] = src[3] | ((uint64_t)best_c << 60);
+  } else {
+    dst[0] = 0; dst[1] = 0; dst[2] = 0;
+    dst[3] = 1ull << 59;                   // fallback (:132-139): 20 BFUs, all indices zero
+  }
+}
+
+}  // namespace
+
+void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
+  const int64_t units = L.frames * L.channels;
+  (void)hipMemsetAsync(L.work_count, 0, sizeof(uint32_t), stream);
+  hipLaunchKernelGGL(k_alloc_first, dim3((unsigned)((units + 63) / 64)), dim3(C1_WAVE), 0, stream, L);
+  const int64_t rest_blocks = std::min<int64_t>((units * 7 + 63) / 64, 256 * 10);
+  hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest_blocks), dim3(C1_WAVE), 0, stream, L);
+  hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, L);
+}

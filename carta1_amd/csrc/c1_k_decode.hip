@@ -1,0 +1,364 @@
+// c1_k_decode.hip -- deserializeFrame + the decode() closure (decoder.js:408-411): one wave per run of units
+#include "c1_device.h"
+
+namespace {
+
+// =====================================================================================================
+// k_decode : deserializeFrame + decode() closure (decoder.js:408-411)
+// =====================================================================================================
+struct alignas(16) DecodeLds {
+  double d1[46];        // stage-1 synthesis delay (qmfDelays.lowBand)
+  double d2[46];        // stage-2 synthesis delay (qmfDelays.midBand)
+  float dhi[39];        // high-band delay
+  float tail[48];       // last 16 IMDCT samples per band (imdctOverlap tails, decoder.js:227-230)
+  uint32_t words[56];   // the unit as big-endian words
+  uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
+  double sf_tab[64];    // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
+  double inv_tab[16];   // coefficient would cost a cache round trip each)
+  union alignas(16) {
+    float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
+    float band[512];    // reconstructed bands: born at the overlap-add
+  } cb;
+  union alignas(16) {
+    struct { union alignas(16) { float2 z[320]; } zz; alignas(16) float mid[512]; } m;   // IMDCT: points (4 pad per 16), outputs
+    struct { alignas(16) double w2[454]; } q2;                   // stage-2 synthesis work buffer (padded 2 per 4)
+    struct { alignas(16) double w1[698]; } q1;                   // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
+  } u;
+};
+
+__device__ __forceinline__ uint32_t get_bits_be(const uint32_t *words, int pos, int nbits) {
+  // unpackBits (bitstream.js:49-70): stops at the end of the 212-byte buffer and returns what it has
+  const int avail = C1_UNIT_BYTES * 8 - pos;
+  if (avail <= 0 || nbits == 0) return 0u;
+  const int nb = nbits < avail ? nbits : avail;
+  const int w = pos >> 5, o = pos & 31;
+  const uint64_t two = ((uint64_t)words[w] << 32) | (uint64_t)words[w + 1];
+  return (uint32_t)((two >> (64 - o - nb)) & ((1ull << nb) - 1ull));
+}
+
+// ---- inverse MDCT in radix-4 rounds: the decoder's mirror of mdct_long_r4 / mdct_mixed_r4 -----------------------
+// Lanes 0..15 band 0, 16..31 band 1, 32..63 band 2, four points per lane; short bands stop after round B.
+// Pre-twiddle of point i reads coefficients 2i and n2-1-2i (mdct.js:161-170; bands 1,2 arrive spectrally
+// reversed, decoder.js:183-186); the post-twiddle keeps the middle half the decoder uses (decoder.js:191-199).
+struct IMixGeometry {
+  int ja[4], jb[4], pre_tab[4];
+  int za, zb, zc, zd, twb, twc, twd;
+  int post_tab[4], ox[4], oy[4];
+  bool is_long, band2;
+};
+__device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes &M) {
+  IMixGeometry G;
+  const int band = lane < 16 ? 0 : (lane < 32 ? 1 : 2);
+  const int g = lane - (band == 0 ? 0 : (band == 1 ? 16 : 32));
+  const bool lng = M.mode_of_band(band) == 0;
+  const int nfft = lng ? (band == 2 ? 128 : 64) : 16, q4 = nfft / 4, n2 = 2 * nfft;
+  const int r = lng ? bitrev(g, band == 2 ? 5 : 4) : bitrev(g & 3, 2);
+  const int blk = lng ? 0 : (g >> 2);
+  const int obase = (band == 0 ? 0 : (band == 1 ? 128 : 256)) + 32 * blk;       // coefficients in, samples out
+  const int tab_base = lng ? (band == 2 ? (int)offsetof(C1DevTables, mdct_inv512) : (int)offsetof(C1DevTables, mdct_inv256))
+                           : (int)offsetof(C1DevTables, mdct_inv64);
+  const int tw_base = (int)offsetof(C1DevTables, fft_tw);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int jp = ((j & 1) << 1) | (j >> 1);
+    const int i = r + q4 * jp;                              // position 4g+j holds point bitrev(4g+j)
+    const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
+    G.ja[j] = obase + (band > 0 ? n2 - 1 - j0 : j0);
+    G.jb[j] = obase + (band > 0 ? n2 - 1 - j1 : j1);
+    G.pre_tab[j] = tab_base + 16 * i;
+  }
+  const int pbase = band == 0 ? 0 : (band == 1 ? 64 : 128);
+  G.za = zslot(pbase + 4 * g);
+  G.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
+  G.twb = tw_base + 16 * (3 + (g & 3));
+  G.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
+  G.twc = tw_base + 16 * (15 + (g & 15));
+  G.zd = zslot(128 + (g & 31));
+  G.twd = tw_base + 16 * (63 + (g & 31));
+  G.is_long = lng;
+  G.band2 = band == 2;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = lng ? (band == 2 ? g + (j == 1 ? 64 : (j == 2 ? 32 : (j == 3 ? 96 : 0))) : g + 16 * j) : (g & 3) + 4 * j;
+    const int idx = (i < nfft / 2) ? 2 * i : (2 * (i - nfft / 2) + nfft);
+    G.post_tab[j] = tab_base + 16 * i;
+    G.ox[j] = obase + n2 - 1 - idx;
+    G.oy[j] = obase + idx;
+  }
+  return G;
+}
+
+// coef: 512 dequantized coefficients; z: 320 slots; mid: 512 outputs.  any_long / band2_long are wave-uniform.
+__device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mid, const IMixGeometry &G, bool any_long,
+                                         bool band2_long, TablesPtr T, TablesRsrc R) {
+  float2 x[4];
+  {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double r = -(double)coef[G.ja[j]], mm = -(double)coef[G.jb[j]];
+      const double2 t = table_pair(R, G.pre_tab[j]);
+      x[j] = make_float2(f32(mm * t.y + r * t.x), f32(mm * t.x - r * t.y));
+    }
+    const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]);
+    const double2 w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
+    const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]);
+    if (__all(r2_unit_ok(x[0], x[1]) && r2_unit_ok(x[2], x[3]))) { r2_butterfly_unit(x[0], x[1]); r2_butterfly_unit(x[2], x[3]); }
+    else { r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0); }
+    if (__all(r2_unit_ok(x[0], x[2]))) r2_butterfly_unit(x[0], x[2]);
+    else r2_butterfly(x[0], x[2], w1);
+    r2_butterfly(x[1], x[3], w2);
+    float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+    dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+    dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+  }
+  __syncthreads();
+  {
+    float2 *p = z + G.zb;
+    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
+    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+    r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+    if (G.is_long) { p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3]; }
+  }
+  if (any_long) {
+    __syncthreads();
+    if (G.is_long) {
+      float2 *p = z + G.zc;
+      const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
+      x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
+      r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
+      r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+      if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
+    }
+    if (band2_long) {
+      __syncthreads();
+      if (G.band2) {
+        const float2 *p = z + G.zd;
+        const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);
+        x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
+        r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wb);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double2 t = table_pair(R, G.post_tab[j]);
+    const double rr = x[j].x, ii = x[j].y;
+    mid[G.ox[j]] = f32(rr * t.x + ii * t.y);                // mdct.js:177-208
+    mid[G.oy[j]] = f32(rr * t.y - ii * t.x);
+  }
+}
+
+__global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
+  __shared__ DecodeLds S;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  const int ch = blockIdx.x % L.channels;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesDecode;
+  float *__restrict__ pcm = L.pcm[ch];
+
+  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
+  for (int i = lane; i < 39; i += 64) S.dhi[i] = 0.0f;
+  for (int i = lane; i < 48; i += 64) S.tail[i] = 0.0f;
+  if (lane < 3) S.words[53 + lane] = 0u;
+  S.sf_tab[lane] = C1_TABLES(L.tables)->scale_factors[lane];
+  if (lane < 16) S.inv_tab[lane] = C1_TABLES(L.tables)->inv_range[lane];
+  // lane-only geometry, computed once per wave
+  uint32_t slot[8];                                  // BFU(6) | index inside the BFU(5) << 6 | short-block position(9) << 11
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const int p = lane0 + 64 * m;                    // coefficient slot in BFU-major order (== long-block position)
+    const int b = bfu_of_slot(p), j = p - kBfuFirst[b];
+    slot[m] = (uint32_t)b | ((uint32_t)j << 6) | ((uint32_t)(kStartShort[b] + j) << 11);
+  }
+  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
+  const IMixGeometry IGL = imix_geometry(lane0, FrameModes{0, 0, 0});   // all-long frames
+  const TablesRsrc RT = tables_rsrc(L.tables);
+  __syncthreads();
+
+  const int64_t f_end = (f0 + kRunFramesDecode < L.frames) ? f0 + kRunFramesDecode : L.frames;
+  for (int64_t f = f0 - 1; f < f_end; ++f) {
+    if (f < -(int64_t)L.halo_units) continue;
+    const bool emit = f >= f0;
+    const int64_t unit = f * L.channels + ch;
+    TablesPtr T = tables_for_this_frame(L.tables);
+    lane = lane_for_this_frame(lane0);
+
+    // ---------------- deserializeFrame (serialization.js:111-176) ----------------
+    if (lane < 53) S.words[lane] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane]);
+    {
+      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      reinterpret_cast<float4 *>(S.cb.coef)[lane] = zero4;
+      reinterpret_cast<float4 *>(S.cb.coef)[64 + lane] = zero4;
+    }
+    __syncthreads();
+    const uint32_t header = S.words[0] >> 16;
+    const int m0 = 2 - (int)((header >> 14) & 3), m1 = 2 - (int)((header >> 12) & 3), m2 = 3 - (int)((header >> 10) & 3);
+    const int n = bfu_amount((header >> 5) & 7);
+    int wl = 0, sfi = 0;
+    if (lane < n) {
+      wl = (int)get_bits_be(S.words, 16 + 4 * lane, 4);
+      sfi = (int)get_bits_be(S.words, 16 + 4 * n + 6 * lane, 6);
+    }
+    const int mybits = wl_bits(wl) * my_size;
+    int scan = mybits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(scan, d);
+      if (lane >= d) scan += o;
+    }
+    if (lane < 52) S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
+    __syncthreads();
+    // ---------------- dequantizationStage (decoder.js:52-98) ----------------
+    const bool all_long = (m0 | m1 | m2) == 0;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int sb = slot[m] & 63, sj = (slot[m] >> 6) & 31;
+      const uint32_t dsc = S.desc[sb];
+      const int bits = dsc & 31;
+      if (bits == 0) continue;                                  // BFU not coded (or beyond nBfu: its word length reads 0)
+      const int sf = (dsc >> 5) & 63;
+      const uint32_t raw = get_bits_be(S.words, (int)(dsc >> 11) + sj * bits, bits);
+      const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;     // bitstream.js:78-82
+      const int32_t range = (1 << (bits - 1)) - 1;
+      float v = 0.0f;                                                                               // quantization.js:65-78
+      if (sf != 0) {
+        const double a = (double)q * S.sf_tab[sf];
+        if (T->dq_fast) {
+          const double y = S.inv_tab[bits - 1], q0 = a * y;
+          v = f32(__builtin_fma(__builtin_fma(-q0, (double)range, a), y, q0));                  // == a / range (checked on the host)
+        } else {
+          v = f32(a / (double)range);
+        }
+      }
+      const int mode = sb >= 36 ? m2 : (sb >= 20 ? m1 : m0);
+      S.cb.coef[mode == 0 ? lane + 64 * m : (int)(slot[m] >> 11)] = v;
+    }
+    __syncthreads();
+
+    // ---------------- imdctStage (decoder.js:116-330) ----------------
+    float *mid = S.u.m.mid;
+    if (all_long) {
+      imdct_r4(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT);
+      __syncthreads();
+      // overlap-add of the first 32 samples of every band (mdct.js:230-245 via decoder.js:203-232) ...
+      if (lane < 32) {
+        const bool lo = lane < 16;
+        const int i = lo ? lane : 31 - lane;
+        const double wa = T->window[i], wb = T->window[31 - i];       // w1 = W[i], w2 = W[31-i]
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+          const double pv = S.tail[16 * b + i], cv = mid[off + 15 - i];
+          S.cb.band[off + lane] = lo ? f32(pv * wb - cv * wa) : f32(pv * wa + cv * wb);
+        }
+      }
+      // ... the rest of the band is invBuf[16 .. S-16) (decoder.js:215-221)
+      if (lane < 48) {
+        const int off = lane < 24 ? 0 : 128, q4 = lane < 24 ? lane : lane - 24;
+        *reinterpret_cast<float4 *>(&S.cb.band[off + 32 + 4 * q4]) = *reinterpret_cast<const float4 *>(&mid[off + 16 + 4 * q4]);
+      }
+      if (lane < 56) *reinterpret_cast<float4 *>(&S.cb.band[256 + 32 + 4 * lane]) = *reinterpret_cast<const float4 *>(&mid[256 + 16 + 4 * lane]);
+    } else {
+    FrameModes M{m0, m1, m2};
+    const IMixGeometry IG = imix_geometry(lane, M);
+    imdct_r4(S.cb.coef, S.u.m.zz.z, mid, IG, m0 == 0 || m1 == 0 || m2 == 0, m2 == 0, T, RT);
+    __syncthreads();
+    // overlap-add (mdct.js:230-245 via decoder.js:203-232 long / :262-300 short)
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int g = lane + 64 * m;
+      const int b = g < 128 ? 0 : (g < 256 ? 1 : 2);
+      const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
+      const int l = g - off;
+      const bool lng = M.mode_of_band(b) == 0;
+      const int q = lng ? 0 : (l >> 5);            // block
+      const int k = lng ? l : (l & 31);            // position inside the block's output
+      float v;
+      if (k < 32) {
+        const float *prev = (q == 0) ? (S.tail + 16 * b) : (mid + off + 32 * (q - 1) + 16);
+        const float *curr = mid + off + 32 * q;
+        if (k < 16) {
+          const double w1 = T->window[k], w2 = T->window[31 - k];
+          v = f32((double)prev[k] * w2 - (double)curr[15 - k] * w1);
+        } else {
+          const int i = 31 - k;
+          const double w1 = T->window[i], w2 = T->window[31 - i];
+          v = f32((double)prev[i] * w1 + (double)curr[15 - i] * w2);
+        }
+      } else {
+        v = mid[off + k - 16];                     // long block only: invBuf[16 .. S-16)
+      }
+      S.cb.band[g] = v;
+    }
+    }
+    __syncthreads();
+    if (lane < 48) {
+      const int b = lane >> 4, k = lane & 15;
+      const int off = b == 0 ? 0 : (b == 1 ? 128 : 256), Sb = b == 2 ? 256 : 128;
+      S.tail[lane] = mid[off + Sb - 16 + k];
+    }
+    __syncthreads();
+
+    // ---------------- qmfSynthesisStage (decoder.js:349-389) ----------------
+    double *w2 = S.u.q2.w2, *w1 = S.u.q1.w1;
+    // high band delay compensation (:360-366): delayed high sample j = j < 39 ? previous tail : band2[j-39]
+    float hi4[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int j = 4 * lane + t;
+      hi4[t] = j < 39 ? S.dhi[j] : S.cb.band[256 + j - 39];
+    }
+    {
+      float keep = 0.0f;
+      if (lane < 39) keep = S.cb.band[256 + 217 + lane];
+      // stage 2: low + mid -> 256 samples (qmf.js:78-84 interleave)
+      if (lane < 46) w2[pidx<2>(lane)] = S.d2[lane];
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const int i = 2 * lane + d;
+        const double l = S.cb.band[i], h = S.cb.band[128 + i];
+        *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 2 * i)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
+      }
+      __syncthreads();
+      if (lane < 39) S.dhi[lane] = keep;
+    }
+    {
+      double s0[2], s1[2];
+      qmf_synthesis_core<2, 2>(w2, lane, T, s0, s1);
+      if (lane < 46) S.d2[lane] = w2[pidx<2>(256 + lane)];
+      __syncthreads();                                    // w1 reuses the memory of w2 from here on
+      if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
+      // stage 1 input: (stage-2 output, delayed high); stage-2 output pair of i: out[2i] = s1, out[2i+1] = s0
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int sidx = 4 * lane + 2 * d + t;          // sample index in the 256-sample low band
+          const double l = (double)f32(t == 0 ? s1[d] : s0[d]);
+          const double h = hi4[2 * d + t];
+          *reinterpret_cast<double2 *>(&w1[pidx<3>(46 + 2 * sidx)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
+        }
+      }
+    }
+    __syncthreads();
+    {
+      double s0[4], s1[4];
+      qmf_synthesis_core<4, 3>(w1, lane, T, s0, s1);
+      if (lane < 46) S.d1[lane] = w1[pidx<3>(512 + lane)];
+      if (emit) {
+        float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512 + 8 * lane);
+        dst[0] = make_float4(f32(s1[0]), f32(s0[0]), f32(s1[1]), f32(s0[1]));
+        dst[1] = make_float4(f32(s1[2]), f32(s0[2]), f32(s1[3]), f32(s0[3]));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream) {
+  const int64_t runs = (L.frames + kRunFramesDecode - 1) / kRunFramesDecode;
+  hipLaunchKernelGGL(k_decode, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+}

@@ -1,0 +1,514 @@
+// c1_k_detect.hip -- transient detection pipeline: features (runs), decisions (per unit), MDCT from the stored bands (per unit)
+#include "c1_device.h"
+
+namespace {
+
+// =====================================================================================================
+// transient detection as its own pipeline: blockSelectorStage (encoder.js:111-152, analysis/transient.js)
+// =====================================================================================================
+//   k_detect_features  one wave per run of frames of one channel (QMF state and the previous frame's magnitudes
+//                      are sequential): QMF analysis, the 128|128|256-point transient FFT, per-bin feature terms and
+//                      the reference's 18 sequential sums.  Writes the raw band samples (2 KB) and the sums (160 B)
+//                      of every frame to the workspace.
+//   k_detect_decide    one lane per sound unit: the scalar feature arithmetic (exp, log10, log1p, sqrt ...; a few
+//                      hundred fp64 instructions that kept 3 of 64 lanes busy inside the frame loop) -> block modes.
+//   k_mdct_bands       one wave per unit, units independent: windowing + MDCT + scale factors from the stored band
+//                      samples of the frame and the 32-sample tails of the previous one.
+// Workspace slots are indexed (frame + 1) * channels + channel: slot row 0 is frame -1 (the PCM halo), which the
+// decision and the overlap of frame 0 need; before the stream start everything is the zero state (buffers.js:30-59).
+constexpr int kFeatureDoubles = kFeatureWsDoubles;   // 18 sums: band-major x {flux, energy, log, linear, low, high}; then nv[3] as int32
+
+struct alignas(16) DetectLds {
+  double d1[46];
+  double d2[46];
+  alignas(16) float hbuf[296];
+  alignas(16) float band[512];
+  union alignas(16) {
+    struct { alignas(16) double w1[698]; } q1;
+    struct { alignas(16) double w2[454]; } q2;
+    struct { alignas(16) float2 z[576]; } t;      // transient FFT points, 1 pad slot per 8
+    struct { alignas(16) double term[4][256]; } tt;
+  } u;
+};
+
+__device__ __forceinline__ int tslot(int pos) { return pos + (pos >> 3); }
+
+// Round A of the transient FFT (performFFT, transient.js:17-35): real input, stages h = 1, 2, 4 on the points at
+// bit-reversed positions 8g..8g+7.  Seven of the twelve butterflies have the twiddle (1, 0); when every sample is
+// finite, not -0 and small enough not to overflow they are exact as Float32 adds (see r2_unit_ok), and the
+// imaginary parts they touch are +0 throughout.
+__device__ __forceinline__ void tfft_round_a(float2 (&x)[8], TablesPtr T) {
+  const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]), w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
+  const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]), w3 = make_double2(T->fft_tw[3][0], T->fft_tw[3][1]);
+  const double2 w4 = make_double2(T->fft_tw[4][0], T->fft_tw[4][1]), w5 = make_double2(T->fft_tw[5][0], T->fft_tw[5][1]);
+  const double2 w6 = make_double2(T->fft_tw[6][0], T->fft_tw[6][1]);
+  uint32_t big = 0;
+  bool neg_zero = false;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t u = __float_as_uint(x[j].x);
+    big = max(big, u & 0x7fffffffu);
+    neg_zero |= (u == 0x80000000u);
+  }
+  const bool exact = big < 0x7b800000u && !neg_zero;      // |x| < 2^120 (also excludes inf and NaN)
+  if (__all(exact)) {
+    // stage 1: all unit; stage 2: (0,2) (4,6) unit; stage 3: (0,4) unit.  Real parts only where the imaginary is +0.
+    float a0 = x[0].x + x[1].x, a1 = x[0].x - x[1].x, a2 = x[2].x + x[3].x, a3 = x[2].x - x[3].x;
+    float a4 = x[4].x + x[5].x, a5 = x[4].x - x[5].x, a6 = x[6].x + x[7].x, a7 = x[6].x - x[7].x;
+    x[0] = make_float2(a0 + a2, 0.0f); x[2] = make_float2(a0 - a2, 0.0f);
+    x[4] = make_float2(a4 + a6, 0.0f); x[6] = make_float2(a4 - a6, 0.0f);
+    x[1] = make_float2(a1, 0.0f); x[3] = make_float2(a3, 0.0f); x[5] = make_float2(a5, 0.0f); x[7] = make_float2(a7, 0.0f);
+    r2_butterfly(x[1], x[3], w2); r2_butterfly(x[5], x[7], w2);
+    const float b0 = x[0].x + x[4].x, b4 = x[0].x - x[4].x;
+    x[0].x = b0; x[4].x = b4;
+  } else {
+    r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0); r2_butterfly(x[4], x[5], w0); r2_butterfly(x[6], x[7], w0);
+    r2_butterfly(x[0], x[2], w1); r2_butterfly(x[1], x[3], w2); r2_butterfly(x[4], x[6], w1); r2_butterfly(x[5], x[7], w2);
+    r2_butterfly(x[0], x[4], w3);
+  }
+  r2_butterfly(x[1], x[5], w4); r2_butterfly(x[2], x[6], w5); r2_butterfly(x[3], x[7], w6);
+}
+// e-output only of a butterfly: the last stage feeds the positive-frequency half (transient.js:29-32)
+__device__ __forceinline__ float2 r2_butterfly_e(const float2 e, const float2 o, const double2 w) {
+  const double er = e.x, ei = e.y, orr = o.x, oi = o.y;
+  const double xr = orr * w.x - oi * w.y;
+  const double xi = orr * w.y + oi * w.x;
+  return make_float2(f32(er + xr), f32(ei + xi));
+}
+
+__global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L, float *bands_ws, double *feat_ws) {
+  __shared__ DetectLds S;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  const int ch = blockIdx.x % L.channels;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
+  const float *__restrict__ pcm = L.pcm[ch];
+  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
+  for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
+  float pmag[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // magnitudes of the previous frame at this lane's four bins
+  // ---- lane-only geometry of the transient FFT: lanes 0..15 band 0 (128 points), 16..31 band 1, 32..63 band 2 (256)
+  const int tband = lane0 < 16 ? 0 : (lane0 < 32 ? 1 : 2);
+  const int tg = lane0 - (tband == 0 ? 0 : (tband == 1 ? 16 : 32));
+  const int tS = tband == 2 ? 32 : 16;                                   // N/8: sample stride of round A, point stride of round C
+  const int t_src = (tband == 0 ? 0 : (tband == 1 ? 128 : 256)) + bitrev(tg, tband == 2 ? 5 : 4);
+  const int t_pbase = tband == 0 ? 0 : (tband == 1 ? 128 : 256);
+  const int t_za = tslot(t_pbase + 8 * tg);
+  const int t_zb = tslot(t_pbase + 64 * (tg >> 3) + (tg & 7));
+  const int t_twb = (int)offsetof(C1DevTables, fft_tw) + 16 * (7 + (tg & 7));
+  const int t_zc = tslot(t_pbase + tg), t_zc_stride = tS + tS / 8;
+  const int t_twc = (int)offsetof(C1DevTables, fft_tw) + 16 * ((tband == 2 ? 127 : 63) + tg), t_twc_stride = 16 * tS;
+  const int t_twd = (int)offsetof(C1DevTables, fft_tw) + 16 * (63 + (tg & 31));
+  const int t_mag = (tband == 0 ? 0 : (tband == 1 ? 64 : 128)) + tg;   // mag index of the lane's first bin; next bins + tS
+  const TablesRsrc RT = tables_rsrc(L.tables);
+  __syncthreads();
+
+  const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
+  int64_t f_first = f0 - 2;                                  // frame -2 rebuilds the QMF delay lines, frame -1 the magnitudes
+  if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;
+  if (f_first > f0) f_first = f0;
+  float4 pre_a, pre_b;
+  {
+    const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
+    pre_a = p4[lane0]; pre_b = p4[64 + lane0];
+  }
+  for (int64_t f = f_first; f < f_end; ++f) {
+    // frame -1 of the whole batch is emitted too (slot row 0): frame 0 needs its features and its band tails
+    const bool emit = (f >= f0) || (f0 == 0 && f == -1);
+    const bool qmf_only = (f == f0 - 2);
+    TablesPtr T = tables_for_this_frame(L.tables);
+    lane = lane_for_this_frame(lane0);
+
+    // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
+    {
+      const float4 a = pre_a, b = pre_b;
+      if (f + 1 < f_end) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
+        pre_a = p4[lane]; pre_b = p4[64 + lane];
+      }
+      double *w1 = S.u.q1.w1;
+      if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
+      const int e0 = 46 + 4 * lane;
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0)]) = make_double2((double)a.x, (double)a.y);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 2)]) = make_double2((double)a.z, (double)a.w);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 256)]) = make_double2((double)b.x, (double)b.y);
+      *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
+    }
+    __syncthreads();
+    {
+      double ev[4], od[4];
+      if (own_block()) qmf_analysis_core<4, 3>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
+      double *w2 = S.u.q2.w2;
+      if (lane < 46) { w2[pidx<2>(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx<3>(512 + lane)]; }
+      float lo[4];
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        lo[d] = f32(ev[d] + od[d]);
+        S.hbuf[39 + 4 * lane + d] = f32(ev[d] - od[d]);
+      }
+      *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 4 * lane)]) = make_double2((double)lo[0], (double)lo[1]);
+      *reinterpret_cast<double2 *>(&w2[pidx<2>(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
+    }
+    __syncthreads();
+    {
+      double ev[2], od[2];
+      if (own_block()) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
+      *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
+      *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
+      *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
+      if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx<2>(256 + lane)];
+    }
+    __syncthreads();
+    {
+      float keep = 0.0f;
+      if (lane < 39) keep = S.hbuf[256 + lane];
+      __syncthreads();
+      if (lane < 39) S.hbuf[lane] = keep;
+    }
+    if (qmf_only) { __syncthreads(); continue; }
+    const int64_t slot = (f + 1) * L.channels + ch;
+    if (emit) {
+      float4 *dst = reinterpret_cast<float4 *>(bands_ws + (slot << 9));
+      const float4 *src = reinterpret_cast<const float4 *>(S.band);
+      dst[lane] = src[lane];
+      dst[64 + lane] = src[64 + lane];
+    }
+
+    // ---------------- performFFT (transient.js:17-35) in radix-8 rounds ----------------
+    float2 x[8];
+    {
+      const float *src = S.band + t_src;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int jr = ((j & 1) << 2) | (j & 2) | (j >> 2);          // bitrev3
+        x[j] = make_float2(src[jr * tS], 0.0f);
+      }
+    }
+    // twiddles of round B are requested before round A computes, those of round C before round B
+    const double2 w8 = table_pair(RT, t_twb), w16a = table_pair(RT, t_twb + 128), w16b = table_pair(RT, t_twb + 256);
+    const double2 w32a = table_pair(RT, t_twb + 384), w32b = table_pair(RT, t_twb + 512);
+    const double2 w32c = table_pair(RT, t_twb + 640), w32d = table_pair(RT, t_twb + 768);
+    tfft_round_a(x, T);
+    float2 *z = S.u.t.z;
+    {
+      float4 *dst = reinterpret_cast<float4 *>(z + t_za);
+#pragma unroll
+      for (int j = 0; j < 4; j++) dst[j] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
+    }
+    __syncthreads();
+    {
+      float2 *p = z + t_zb;                                    // stages 8, 16, 32 on the points p + 8j
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[j] = p[9 * j];
+      r2_butterfly(x[0], x[1], w8); r2_butterfly(x[2], x[3], w8); r2_butterfly(x[4], x[5], w8); r2_butterfly(x[6], x[7], w8);
+      r2_butterfly(x[0], x[2], w16a); r2_butterfly(x[1], x[3], w16b); r2_butterfly(x[4], x[6], w16a); r2_butterfly(x[5], x[7], w16b);
+      r2_butterfly(x[0], x[4], w32a); r2_butterfly(x[1], x[5], w32b); r2_butterfly(x[2], x[6], w32c); r2_butterfly(x[3], x[7], w32d);
+#pragma unroll
+      for (int j = 0; j < 8; j++) p[9 * j] = x[j];
+    }
+    const double2 wDa = table_pair(RT, t_twd), wDb = table_pair(RT, t_twd + 512);
+    const double2 wC0 = table_pair(RT, t_twc), wC1 = table_pair(RT, t_twc + t_twc_stride);
+    const double2 wC2 = table_pair(RT, t_twc + 2 * t_twc_stride), wC3 = table_pair(RT, t_twc + 3 * t_twc_stride);
+    __syncthreads();
+    float mg[4];
+    {
+      // points g + tS*t, t = 0..7.  Band 2 first runs stage 64 on them; then stage N/2 (64 for the 128-point
+      // transforms, 128 for the 256-point one) pairs (t, t+4) and only its e-outputs, the bins g + tS*t, are needed
+      const float2 *p = z + t_zc;
+#pragma unroll
+      for (int t = 0; t < 8; t++) x[t] = p[t * t_zc_stride];
+      if (tband == 2) {
+        r2_butterfly(x[0], x[2], wDa); r2_butterfly(x[1], x[3], wDb); r2_butterfly(x[4], x[6], wDa); r2_butterfly(x[5], x[7], wDb);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float2 e = r2_butterfly_e(x[i], x[i + 4], i == 0 ? wC0 : (i == 1 ? wC1 : (i == 2 ? wC2 : wC3)));
+        const double r = e.x, im = e.y;
+        mg[i] = f32(sqrt(r * r + im * im));
+      }
+    }
+    __syncthreads();                                           // the per-bin terms reuse the memory of the points
+    if (emit) {
+      // ---------------- feature terms per bin, then the reference's sequential sums ----------------
+      bool valid[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int g = t_mag + i * tS;
+        const double cm = (double)mg[i], pm = (double)pmag[i];
+        const double diff = cm - pm;
+        valid[i] = cm > 1e-10;
+        S.u.tt.term[0][g] = diff > 0 ? diff : 0.0;            // spectral flux terms (transient.js:96-106)
+        S.u.tt.term[1][g] = cm * cm;                          // energy terms (exact product)
+        S.u.tt.term[2][g] = valid[i] ? log(cm) : 0.0;         // flatness terms (transient.js:126-133)
+        S.u.tt.term[3][g] = valid[i] ? cm : 0.0;
+      }
+      int nv_all = 0;
+      {
+        uint64_t m = 0;
+        int n0 = 0, n1 = 0, n2 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          m = __ballot(valid[i]);
+          n0 += __popc((uint32_t)m & 0xffffu); n1 += __popc((uint32_t)m >> 16); n2 += __popcll(m >> 32);
+        }
+        nv_all = lane == 0 ? n0 : (lane == 1 ? n1 : n2);
+      }
+      __syncthreads();
+      double *feat = feat_ws + slot * kFeatureDoubles;
+      if (lane < 18) {
+        // 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high}), index ascending
+        const int b = lane / 6, kind = lane - 6 * b;
+        const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
+        const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
+        const int start = g0 + (kind == 5 ? n / 2 : 0);
+        const int len = kind >= 4 ? n / 2 : n;
+        const double2 *arr = reinterpret_cast<const double2 *>(S.u.tt.term[which] + start);
+        double acc = 0.0;
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++) {
+          if (32 * blk < len) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { const double2 v = arr[16 * blk + i]; acc += v.x; acc += v.y; }
+          }
+        }
+        feat[lane] = acc;
+      }
+      if (lane < 3) reinterpret_cast<int *>(feat + 18)[lane] = nv_all;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) pmag[i] = mg[i];
+    __syncthreads();
+  }
+}
+
+// features of one band of one frame from its sums (transient.js:88-189); `flux` needs the previous magnitudes and
+// is only meaningful for the current frame
+struct BandFeatures { double flux, flat, hf, energy; };
+__device__ __forceinline__ BandFeatures band_features(const double *s, int nv) {
+  BandFeatures r;
+  const double s_flux = s[0], s_e = s[1], s_log = s[2], s_lin = s[3], s_lo = s[4], s_hi = s[5];
+  double norm = sqrt(s_e);
+  if (!(norm != 0.0)) norm = 1e-6;                       // `Math.sqrt(e) || 1e-6`
+  r.flux = s_flux / norm;
+  r.flat = 0.0;                                          // calculateSpectralFlatness :120-141
+  if (nv > 0) {
+    const double gm = exp(s_log / (double)nv), am = s_lin / (double)nv;
+    r.flat = am > 1e-10 ? gm / am : 0.0;
+  }
+  const double tot = s_lo + s_hi;                        // calculateHighFrequencyRatio :149-164
+  r.hf = tot > 0 ? s_hi / tot : 0.0;
+  r.energy = s_e;
+  return r;
+}
+
+// block modes of one sound unit from the feature sums of its frame and of the previous one (encoder.js:137-143)
+__device__ __forceinline__ int detect_decide_unit(const double *__restrict__ feat_ws, int channels, int64_t unit, int halo_frames,
+                                                       const C1DevTables *tables, const C1DevEncOpts *opts) {
+  const int64_t f = unit / channels;
+  const double *cur = feat_ws + (unit + channels) * kFeatureDoubles;
+  const double *prev = cur - (int64_t)channels * kFeatureDoubles;
+  const bool have_prev = (f - 1 >= -(int64_t)halo_frames);      // else the zero state of a fresh BufferPool
+  const double log1p10 = tables->log1p10, threshold = opts->threshold;
+  int mode_byte = 0;
+  for (int b = 0; b < 3; b++) {
+    const BandFeatures c = band_features(cur + 6 * b, reinterpret_cast<const int *>(cur + 18)[b]);
+    double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;
+    if (have_prev) {
+      const BandFeatures p = band_features(prev + 6 * b, reinterpret_cast<const int *>(prev + 18)[b]);
+      prev_flat = p.flat; prev_hf = p.hf; prev_e = p.energy;
+    }
+    const double ce = c.energy > 1e-10 ? c.energy : 1e-10;     // calculateEnergyChange :172-189
+    const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
+    const double db = 10.0 * log10(ce / pe);
+    const double e_change = db > 0 ? db : 0.0;
+    const double flat_c = sqrt(fabs(c.flat - prev_flat));       // calculateTransientScore :197-226
+    const double hf_c = log1p(fabs(c.hf - prev_hf) * 10.0) / log1p10;
+    const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
+    const double score = (c.flux + flat_c + hf_c + e_c) / 4.0;
+    const int mode = (score > threshold) ? (b + 1 > 2 ? b + 1 : 2) : 0;   // encoder.js:143
+    mode_byte |= mode << (2 * b);
+  }
+  return mode_byte;
+}
+
+__global__ __launch_bounds__(256) void k_detect_decide(const double *__restrict__ feat_ws, int channels, int64_t frames,
+                                                        int halo_frames, const C1DevTables *tables, const C1DevEncOpts *opts,
+                                                        uint8_t *__restrict__ modes, uint32_t *__restrict__ lists) {
+  const int64_t unit = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t units = frames * channels;
+  const bool live = unit < units;
+  int mode_byte = 0;
+  if (live) mode_byte = detect_decide_unit(feat_ws, channels, unit, halo_frames, tables, opts);
+  if (live) modes[unit] = (uint8_t)mode_byte;
+  // two work lists for the MDCT stage: all-long units and units with a short band (lists[0], lists[1] = counts,
+  // then `units` entries each); one atomic per wave and list
+  uint32_t *list_long = lists + 4, *list_mixed = lists + 4 + units;
+  const bool is_long = live && mode_byte == 0, is_mixed = live && mode_byte != 0;
+  const uint64_t ml = __ballot(is_long), mm = __ballot(is_mixed);
+  const int lane = threadIdx.x & 63;
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint32_t base_l = 0, base_m = 0;
+  if (lane == 0) {
+    if (ml) base_l = atomicAdd(&lists[0], (uint32_t)__popcll(ml));
+    if (mm) base_m = atomicAdd(&lists[1], (uint32_t)__popcll(mm));
+  }
+  base_l = __shfl(base_l, 0); base_m = __shfl(base_m, 0);
+  if (is_long) list_long[base_l + __popcll(ml & below)] = (uint32_t)unit;
+  if (is_mixed) list_mixed[base_m + __popcll(mm & below)] = (uint32_t)unit;
+}
+
+
+
+struct alignas(16) MdctLds {
+  alignas(16) float band[512];
+  alignas(16) float ovl[96];
+  alignas(4) uint8_t sfi[64];
+  union alignas(16) {
+    struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;   // long-block inputs
+    struct { alignas(16) float in[kStageFloats]; } g;                                                    // staging of frames with short blocks
+    struct { alignas(16) float coef[512]; } c;
+  } a;
+  union alignas(16) {
+    float2 z[320];
+  } zz;
+};
+
+// mdctStage + scale factors of one sound unit from the stored band samples; units are independent.  Two
+// instantiations work through the two lists k_detect_decide wrote: LONG (all three bands long, the common case;
+// lean enough for 4 waves per SIMD) and mixed (at least one short band).
+template <bool LONG>
+__global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, const float *__restrict__ bands_ws,
+                                                                         const uint8_t *__restrict__ modes,
+                                                                         const uint32_t *__restrict__ lists) {
+  __shared__ MdctLds S;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  const int64_t units = L.frames * L.channels;
+  const uint32_t count = lists[LONG ? 0 : 1];
+  const uint32_t *__restrict__ list = lists + 4 + (LONG ? 0 : units);
+  const R4Geometry G4 = r4_geometry(lane0);          // LONG
+  const SfLong SFL = sf_long_geometry(lane0);        // LONG
+  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
+  const TablesRsrc RT = tables_rsrc(L.tables);
+  // tails of the previous frame: lane < 24 loads four samples of band lane / 8
+  const int tail_band = lane0 >> 3, tail_k = 4 * (lane0 & 7);
+  const int tail_src = (tail_band == 0 ? 96 : (tail_band == 1 ? 224 : 480)) + tail_k;
+  // window values the lane needs every unit: fixed per lane, read once
+  const double wt0 = C1_TABLES(L.tables)->window[tail_k & 31], wt1 = C1_TABLES(L.tables)->window[(tail_k + 1) & 31];
+  const double wt2 = C1_TABLES(L.tables)->window[(tail_k + 2) & 31], wt3 = C1_TABLES(L.tables)->window[(tail_k + 3) & 31];
+  const double win_hi = C1_TABLES(L.tables)->window[31 - (lane0 & 31)];
+  uint32_t i = blockIdx.x;
+  if (i >= count) return;
+  float4 pre_a, pre_b, pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int pre_mode = 0;
+  auto fetch = [&](int64_t u) {
+    const int64_t slot = u + L.channels;
+    const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
+    pre_a = p4[lane0]; pre_b = p4[64 + lane0];
+    const bool have_prev = ((L.channels == 2 ? u >> 1 : u) - 1 >= -(int64_t)L.halo_frames);
+    pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (have_prev && lane0 < 24) pre_t = *reinterpret_cast<const float4 *>(bands_ws + ((slot - L.channels) << 9) + tail_src);
+    if (!LONG) pre_mode = modes[u];
+  };
+  int64_t unit = list[i];
+  int64_t unit_next = i + gridDim.x < count ? list[i + gridDim.x] : 0;
+  fetch(unit);
+  for (; i < count; i += gridDim.x) {
+    TablesPtr T = tables_for_this_frame(L.tables);
+    lane = lane_for_this_frame(lane0);
+    const float4 a = pre_a, b = pre_b, t = pre_t;
+    const int mode_byte = LONG ? 0 : __builtin_amdgcn_readfirstlane(pre_mode);
+    const int64_t unit_now = unit;
+    if (i + gridDim.x < count) {
+      unit = unit_next;
+      fetch(unit);
+      if (i + 2 * gridDim.x < count) unit_next = list[i + 2 * gridDim.x];
+    }
+    reinterpret_cast<float4 *>(S.band)[lane] = a;
+    reinterpret_cast<float4 *>(S.band)[64 + lane] = b;
+    if (lane < 24) {
+      // mdctOverlap of the previous frame (applyTailWindowing, encoder.js:309-316): W[k] * tail sample
+      float4 o;
+      o.x = f32(wt0 * (double)t.x); o.y = f32(wt1 * (double)t.y);
+      o.z = f32(wt2 * (double)t.z); o.w = f32(wt3 * (double)t.w);
+      reinterpret_cast<float4 *>(S.ovl)[lane] = o;
+    }
+    __syncthreads();
+    const FrameModes M{mode_byte & 3, (mode_byte >> 2) & 3, (mode_byte >> 4) & 3};
+    float *coef = S.a.c.coef;
+    if constexpr (LONG) {
+      // ---------------- long blocks (encoder.js:228-258) ----------------
+      float *in0 = S.a.i.in0, *in1 = S.a.i.in1, *in2 = S.a.i.in2;
+      const float *band_ = S.band;
+      if (lane < 32) {
+        const double w_hi = win_hi;
+        const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
+        in0[48 + lane] = S.ovl[lane]; in1[48 + lane] = S.ovl[32 + lane]; in2[112 + lane] = S.ovl[64 + lane];
+        in0[80 + 96 + lane] = f32(x0 * w_hi);
+        in1[80 + 96 + lane] = f32(x1 * w_hi);
+        in2[144 + 224 + lane] = f32(x2 * w_hi);
+      }
+      {
+        const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lane < 48) {
+          float *inb = lane < 24 ? in0 : in1;
+          const int q = lane < 24 ? lane : lane - 24;                 // 24 float4 per band: [0,48) and [208,256)
+          *reinterpret_cast<float4 *>(&inb[q < 12 ? 4 * q : 208 + 4 * (q - 12)]) = zero4;
+        }
+        if (lane < 56) *reinterpret_cast<float4 *>(&in2[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
+        if (lane < 48) {
+          *reinterpret_cast<float2 *>(&in0[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[2 * lane]);
+          *reinterpret_cast<float2 *>(&in1[80 + 2 * lane]) = *reinterpret_cast<const float2 *>(&band_[128 + 2 * lane]);
+        }
+        if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
+      }
+      __syncthreads();
+      mdct_long_r4(in0, S.zz.z, coef, G4, T, RT, r4_early(G4, RT));
+      __syncthreads();
+    } else {
+      const MixGeometry GM = mix_geometry(lane, M);
+      mix_stage(S.band, S.ovl, S.a.g.in, M, lane, RT);
+      __syncthreads();
+      mdct_mixed_r4(S.a.g.in, S.zz.z, coef, GM, M.m0 == 0 || M.m1 == 0 || M.m2 == 0, M.m2 == 0, T, RT);
+      __syncthreads();
+    }
+    // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+    {
+      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit_now << 9));
+      const float4 *src = reinterpret_cast<const float4 *>(coef);
+      dst[lane] = src[lane];
+      dst[64 + lane] = src[64 + lane];
+    }
+    if constexpr (LONG) {
+      sf_long(coef, S.sfi, SFL, T);
+      if (lane >= 60) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60) % 3] = 0;   // modes byte (all long) and padding
+    } else {
+      if (lane < 52) {
+        const int start = M.mode_of_band(band_of_bfu(lane)) == 0 ? my_long : my_short;
+        const int n = my_size;
+        float mx = 0.0f;
+        for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
+        S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
+      } else {
+        S.sfi[lane] = lane == 52 ? (uint8_t)mode_byte : 0;
+      }
+    }
+    __syncthreads();
+    if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit_now * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
+                       hipStream_t stream) {
+  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong, units = L.frames * L.channels;
+  (void)hipMemsetAsync(lists_ws, 0, 4 * sizeof(uint32_t), stream);
+  hipLaunchKernelGGL(k_detect_features, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
+  hipLaunchKernelGGL(k_detect_decide, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, feat_ws, L.channels, L.frames,
+                     L.halo_frames, L.tables, L.opts, modes_ws, lists_ws);
+  // both list kernels size their grids for the whole batch and stop at the device-side count
+  const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
+  hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+  hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+}

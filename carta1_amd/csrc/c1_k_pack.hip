@@ -1,0 +1,219 @@
+// c1_k_pack.hip -- quantize + MSB-first packing of the 212-byte sound unit (quantization.js:34-56, serialization.js:41-98)
+#include "c1_device.h"
+
+namespace {
+
+// =====================================================================================================
+// k_pack : quantize (quantization.js:34-56) + serializeFrame (serialization.js:41-98)
+// =====================================================================================================
+// ECMAScript ToInt32 of a double (what `| 0` does): truncate, wrap modulo 2^32.
+__device__ __forceinline__ int32_t to_int32(double x) {
+  const double t = trunc(x);
+  if (fabs(t) < 2147483648.0) return (int32_t)t;
+  const uint64_t bits = (uint64_t)__double_as_longlong(t);
+  const int e = (int)((bits >> 52) & 0x7ff);
+  if (e == 0x7ff) return 0;                                  // NaN, +-Infinity -> 0
+  const int sh = e - 1075;                                   // value = mant * 2^sh, sh >= -21 here
+  const uint64_t mant = (bits & 0xfffffffffffffull) | (1ull << 52);
+  uint32_t low;
+  if (sh >= 32) low = 0u;
+  else if (sh >= 0) low = (uint32_t)(mant << sh);
+  else low = (uint32_t)(mant >> (-sh));
+  return (int32_t)((bits >> 63) ? (0u - low) : low);
+}
+
+__device__ __forceinline__ void put_bits_be(uint32_t *words, int pos, uint32_t v, int nbits) {
+  // MSB-first (bitstream.js:15-40); words are big-endian 32-bit groups, assembled with LDS atomics
+  const int w = pos >> 5, o = pos & 31;
+  if (o + nbits <= 32) atomicOr(&words[w], v << (32 - o - nbits));
+  else {
+    const int lo = o + nbits - 32;
+    atomicOr(&words[w], v >> lo);
+    atomicOr(&words[w + 1], v << (32 - lo));
+  }
+}
+
+// wave-level fence: LDS operations of one wave execute in issue order, so lanes of the same wave only
+// need the compiler not to reorder across this point (no s_barrier: waves of a block run independently)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kPackWaves = 4;            // independent waves per workgroup, one sound unit at a time each
+constexpr int kPackBlocks = 2048;        // persistent grid: waves stride over the units
+
+struct PackLds {
+  uint32_t words[56];         // the unit as big-endian 32-bit groups
+  uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
+  double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
+};
+
+// One wave per sound unit.  A lane owns 8 consecutive coefficient slots (BFU-major order == bitstream
+// order), quantizes them (quantization.js:34-56) and appends the mantissas MSB-first to a 64-bit
+// accumulator (serialization.js:79-91).  Completed 32-bit groups that lie wholly inside the lane's bit
+// range are plain LDS stores; only the first and last, which neighbours share, are atomic ORs.
+// The loop is software pipelined: the allocation/side records of the unit two steps ahead and the
+// coefficients of the next unit are in flight while the current unit is packed.
+struct PackHeader {   // what a lane needs of one unit's allocation and side records
+  uint32_t al_wl;     // allocation dword holding this lane's word-length nibble        (al[lane >> 3])
+  uint32_t al7;       // last allocation dword: amount index, fallback flag
+  uint32_t sd_sf;     // side dword holding this lane's scale-factor index              (side[lane >> 2])
+  uint32_t sd_q;      // side dword lane & 15 (four scale factors for the 24-bit field, modes in dword 13)
+  uint32_t al_a, al_b;   // allocation dwords (lane - 1) & 7 and lane & 7 (word-length bytes, lanes 0..7)
+};
+__device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, int64_t unit, int lane) {
+  const uint32_t *al = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes);
+  const uint32_t *side = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes);
+  PackHeader h;
+  h.al_wl = al[lane >> 3];
+  h.al7 = al[7];
+  h.sd_sf = side[lane >> 2];
+  h.sd_q = side[lane & 15];
+  h.al_a = al[(lane + 7) & 7];
+  h.al_b = al[lane & 7];
+  return h;
+}
+
+// ALL_LONG: the caller knows every unit of the batch has modes [0,0,0] (fixed block modes): coefficient order ==
+// slot order, no per-slot position tables
+template <bool ALL_LONG>
+__global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack(C1EncodeLaunch L) {
+  __shared__ PackLds lds[kPackWaves];
+  __shared__ double norm_s[64 * 16];        // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
+  TablesPtr T = C1_TABLES(L.tables);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PackLds &S = lds[wave];
+  for (int i = threadIdx.x; i < 64 * 16; i += C1_WAVE * kPackWaves) norm_s[i] = T->norm[i];
+  __syncthreads();
+  // which BFU / which coefficient each of this lane's 8 slots is, and where it sits for long / short blocks
+  int slot_b[8], slot_j[8], at_long[8], at_short[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const int p = 8 * lane + m;
+    slot_b[m] = bfu_of_slot(p);
+    slot_j[m] = p - kBfuFirst[slot_b[m]];
+    at_long[m] = ALL_LONG ? 0 : kStartLong[slot_b[m]] + slot_j[m];
+    at_short[m] = ALL_LONG ? 0 : kStartShort[slot_b[m]] + slot_j[m];
+  }
+  const int my_size = lane < 52 ? kSpecs[lane] : 0;
+  const int my_long = lane < 52 ? kStartLong[lane] : 0, my_short = lane < 52 ? kStartShort[lane] : 0;
+  const int64_t units_total = L.frames * L.channels;
+  const int64_t stride = (int64_t)gridDim.x * kPackWaves;
+  const int64_t u_first = (int64_t)blockIdx.x * kPackWaves + wave;
+  auto load_coefs = [&](int64_t unit, uint32_t modes_dword, float (&x)[8]) {
+    const float *coefs = L.coefs + (unit << 9);
+    const int modes = (int)(modes_dword & 0xff);
+    if (ALL_LONG || modes == 0) {   // all long: coefficient order == slot order
+      const float4 a = reinterpret_cast<const float4 *>(coefs)[2 * lane], c = reinterpret_cast<const float4 *>(coefs)[2 * lane + 1];
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+    } else {
+      const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int mode = slot_b[m] >= 36 ? m2 : (slot_b[m] >= 20 ? m1 : m0);
+        x[m] = coefs[mode == 0 ? at_long[m] : at_short[m]];
+      }
+    }
+  };
+  if (u_first >= units_total) return;
+  PackHeader h0 = pack_load_header(L, u_first, lane);
+  PackHeader h1 = pack_load_header(L, u_first + stride < units_total ? u_first + stride : u_first, lane);
+  float x[8];
+  load_coefs(u_first, __shfl(h0.sd_q, 13), x);
+  for (int64_t unit = u_first; unit < units_total; unit += stride) {
+    // ---- issue the loads of the units ahead ----
+    const int64_t u1 = unit + stride, u2 = unit + 2 * stride;
+    PackHeader h2 = pack_load_header(L, u2 < units_total ? u2 : unit, lane);
+    float xn[8];
+    load_coefs(u1 < units_total ? u1 : unit, __shfl(h1.sd_q, 13), xn);
+    // ---- this unit ----
+    const uint32_t a7 = h0.al7;
+    const bool fallback = (a7 >> 27) & 1;
+    const int amount = (int)(a7 >> 28) & 7;
+    const int n = bfu_amount(amount);
+    const int modes = ALL_LONG ? 0 : (int)(__shfl(h0.sd_q, 13) & 0xff);
+    const int m0 = modes & 3, m1 = (modes >> 2) & 3, m2 = (modes >> 4) & 3;
+    if (lane < 56) S.words[lane] = 0;
+    int wl = 0, sf = 0;
+    if (lane < 52) {
+      wl = lane < n ? (int)((h0.al_wl >> ((lane & 7) * 4)) & 15) : 0;
+      sf = fallback ? 0 : (int)((h0.sd_sf >> ((lane & 3) * 8)) & 63);
+    }
+    // bit offset of every BFU's mantissas: exclusive prefix sum of bits*size over the wave
+    const int bits_b = wl_bits(wl);
+    const int mybits = bits_b * my_size;
+    int scan = mybits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(scan, d);
+      if (lane >= d) scan += o;
+    }
+    if (lane < 52) {
+      const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
+      S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
+      S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
+    }
+    wave_sync();
+    // header (serialization.js:46-53) and word-length indices (:55-64): the 4-bit indices are already
+    // packed two per byte in the allocation record, low nibble first; the unit wants the high nibble first
+    if (lane < 8) {
+      auto wl_be = [](uint32_t v) -> uint32_t { return __builtin_bswap32(((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu)); };
+      const uint32_t header = ((uint32_t)(2 - m0) << 14) | ((uint32_t)(2 - m1) << 12) | ((uint32_t)(3 - m2) << 10) | ((uint32_t)amount << 5);
+      const uint32_t prev = lane == 0 ? (header & 0xffffu) : wl_be(h0.al_a);      // word-length bytes 4(lane-1)..
+      const uint32_t cur = lane == 7 ? 0u : wl_be(h0.al_b);                       // last dword carries flags, no indices
+      atomicOr(&S.words[lane], (prev << 16) | (cur >> 16));
+    }
+    // scale-factor indices (:66-77): four 6-bit fields = 24 bits per lane
+    if (lane < (n >> 2)) {
+      const uint32_t q = fallback ? 0u : h0.sd_q;
+      const uint32_t t = ((q & 63u) << 18) | (((q >> 8) & 63u) << 12) | (((q >> 16) & 63u) << 6) | ((q >> 24) & 63u);
+      put_bits_be(S.words, 16 + 4 * n + 24 * lane, t, 24);
+    }
+    // mantissas
+    uint64_t acc = 0;
+    int cnt = -1, wi = 0;
+    bool first = true;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const uint32_t dsc = S.desc[slot_b[m]];
+      const int bits = dsc & 31;
+      if (cnt < 0 && bits != 0) {                               // the lane's first coded slot fixes its bit cursor
+        const int pos = (int)((dsc >> 5) & 0x7ff) + slot_j[m] * bits;
+        cnt = pos & 31;                                         // phantom zero bits in front: a neighbour's bits
+        wi = pos >> 5;
+      }
+      const double xs = (double)x[m] * S.normd[slot_b[m]];
+      const double v = xs + (xs >= 0 ? 0.5 : -0.5);            // round half away from zero ...
+      int32_t y = (int32_t)v;                                  // ... then `| 0`: truncation; exact wrap below
+      if (__builtin_expect(!(fabs(v) < 2147483648.0), 0)) y = to_int32(v);
+      const int32_t range = (1 << (bits > 0 ? bits - 1 : 0)) - 1;
+      y = y > range ? range : (y < -range ? -range : y);
+      acc = (acc << bits) | ((uint32_t)y & ((1u << bits) - 1u));
+      cnt += bits != 0 ? bits : 0;
+      if (cnt >= 32) {                                          // a 32-bit group is complete
+        cnt -= 32;
+        const uint32_t w = (uint32_t)(acc >> cnt);
+        acc &= (1ull << cnt) - 1ull;
+        if (first) atomicOr(&S.words[wi], w); else S.words[wi] = w;
+        first = false;
+        wi++;
+      }
+    }
+    if (cnt > 0) atomicOr(&S.words[wi], (uint32_t)(acc << (32 - cnt)));
+    wave_sync();
+    if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
+    wave_sync();
+    h0 = h1; h1 = h2;
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[m] = xn[m];
+  }
+}
+
+}  // namespace
+
+void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream) {
+  const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
+  if (all_long) hipLaunchKernelGGL((k_pack<true>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_pack<false>), grid, block, 0, stream, L);
+}
