@@ -510,3 +510,35 @@ def test_wav_body_to_units_and_back_in_one_call(ctx, bits, ch):
     back = ctx.decode_wav16(want, ch)
     assert back.shape == (len(pcm_want[0]), ch)
     assert np.array_equal(back.reshape(-1), O.pcm_to_int16(pcm_want))
+
+
+def test_two_contexts_in_two_threads(ctx):
+    """Distinct contexts are independent (own stream, own workspace): two host threads encoding and decoding at the
+    same time get the bytes a single thread gets."""
+    import threading
+    import carta1_amd as c1
+    data = [[O.gen_pinkT(61 + 2 * k, 700 * 512), O.gen_white(62 + 2 * k, 700 * 512)] for k in range(2)]
+    opts = [c1.EncoderOptions(), c1.EncoderOptions({'fixedBlockModes': [2, 2, 3]})]
+    want = [ctx.encode(data[k], opts[k]) for k in range(2)]
+    want_pcm = [ctx.decode(want[k], 2) for k in range(2)]
+    got, got_pcm, errors = [None, None], [None, None], []
+
+    def work(k):
+        try:
+            c = c1.Context(0)
+            for _ in range(5):
+                got[k] = c.encode(data[k], opts[k])
+                got_pcm[k] = c.decode(got[k], 2)
+            c.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert np.array_equal(got[k], want[k])
+        for c in range(2):
+            assert np.array_equal(got_pcm[k][c].view(np.uint32), want_pcm[k][c].view(np.uint32))
