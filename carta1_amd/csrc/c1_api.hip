@@ -725,6 +725,16 @@ int ensure_ring(c1_ctx *ctx, size_t bytes) {
   return C1_OK;
 }
 
+// Leaves no copy in flight into or out of the caller's host memory, whichever way the function returns.
+struct StreamDrain {
+  c1_ctx *ctx;
+  ~StreamDrain() {
+    if (ctx->s_up) (void)hipStreamSynchronize(ctx->s_up);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->s_down) (void)hipStreamSynchronize(ctx->s_down);
+  }
+};
+
 // upload of chunk i+1 | kernels of chunk i | download of chunk i-1, two staging sets.  The download of chunk i-1 is
 // queued after the upload and the kernels of chunk i, so a download into pageable memory (which blocks the host
 // until it is done) still leaves the other two stages of the next chunk in flight.
@@ -736,6 +746,7 @@ int encode_batch_streamed(c1_ctx *ctx, const float *const *pcm, int channels, in
   const size_t set_bytes = in_bytes * channels + out_bytes;
   int rc = ensure_ring(ctx, 2 * set_bytes);
   if (rc) return rc;
+  StreamDrain drain{ctx};
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
     const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
@@ -783,6 +794,7 @@ int decode_batch_streamed(c1_ctx *ctx, const uint8_t *units, int channels, int64
   const size_t set_bytes = in_bytes + out_bytes * channels;
   int rc = ensure_ring(ctx, 2 * set_bytes);
   if (rc) return rc;
+  StreamDrain drain{ctx};
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
     const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
@@ -945,6 +957,7 @@ int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int chan
   const size_t out_bytes = ((size_t)chunk * channels * C1_UNIT_BYTES + 255) & ~(size_t)255;
   const size_t set_bytes = raw_bytes + pcm_bytes * channels + out_bytes;
   if ((rc = ensure_ring(ctx, 2 * set_bytes))) return rc;
+  StreamDrain drain{ctx};
   const uint8_t *src = static_cast<const uint8_t *>(interleaved);
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
@@ -1004,6 +1017,7 @@ int c1_decode_wav16_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64
   const size_t out_bytes = (size_t)chunk * 512 * channels * sizeof(int16_t);
   const size_t set_bytes = in_bytes + pcm_bytes * channels + out_bytes;
   if ((rc = ensure_ring(ctx, 2 * set_bytes))) return rc;
+  StreamDrain drain{ctx};
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
     const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
