@@ -7,3 +7,4 @@ libcarta1_hip.so; nothing here falls back to the CPU.
 from .capi import Carta1Error, FRAME, UNIT_BYTES, SIGNAL_WHITE, SIGNAL_PINK_BURSTS  # noqa: F401
 from .codec import (Context, EncoderOptions, encode_pcm, decode_units, encode_aea_pcm, decode_aea_pcm,  # noqa: F401
                     EncoderStream, DecoderStream, aea_header, parse_aea_header, pinned_empty)
+from .shard import shard_plan, encode_sharded, decode_sharded  # noqa: F401,E402

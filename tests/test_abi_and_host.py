@@ -178,3 +178,14 @@ def test_page_locked_allocation_needs_a_device():
     assert lib.c1_host_alloc(1 << 20, C.byref(p)) != 0 and not p.value
     assert b'no HIP device' in lib.c1_last_error()
     assert lib.c1_host_free(None) == 0
+
+
+def test_shard_plan_tiles_the_batch():
+    from carta1_amd import shard_plan
+    for frames, shards, hist in ((100, 8, 2), (7, 8, 1), (1048576, 8, 2), (5, 1, 2), (0, 4, 1)):
+        plan = shard_plan(frames, shards, hist)
+        assert plan[0][0] == 0 and plan[-1][1] == frames
+        assert all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+        sizes = [b - a for a, b, _ in plan]
+        assert max(sizes) - min(sizes) <= 1
+        assert all(h == min(hist, a) for a, _, h in plan)

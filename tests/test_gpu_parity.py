@@ -542,3 +542,19 @@ def test_two_contexts_in_two_threads(ctx):
         assert np.array_equal(got[k], want[k])
         for c in range(2):
             assert np.array_equal(got_pcm[k][c].view(np.uint32), want_pcm[k][c].view(np.uint32))
+
+
+def test_sharded_encode_and_decode_equal_one_device(ctx):
+    """encode_sharded / decode_sharded: contiguous frame ranges with their halo, one host thread and one context per
+    shard (here all on device 0), outputs concatenated -- the bytes of a single-device call."""
+    import carta1_amd as c1
+    frames = 999
+    chs = [O.gen_pinkT(71, frames * 512), O.gen_pinkT(72, frames * 512)]
+    for opts in ({}, {'fixedBlockModes': [0, 0, 0]}, {'fixedBlockModes': [2, 2, 3]}):
+        want = ctx.encode(chs, c1.EncoderOptions(opts))
+        got = c1.encode_sharded(chs, c1.EncoderOptions(opts), devices=(0, 0, 0))
+        assert np.array_equal(got, want), opts
+    pcm_want = ctx.decode(want, 2)
+    pcm_got = c1.decode_sharded(want, 2, devices=(0, 0, 0, 0))
+    for c in range(2):
+        assert np.array_equal(pcm_got[c].view(np.uint32), pcm_want[c].view(np.uint32))
