@@ -91,7 +91,9 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
   // greedy spending loop (:244-278): the root either takes its next priority or leaves the heap (does not
   // fit :251-258, or reached the last word length :271-277); then one sift.
   uint32_t r0 = hp[0], r1 = hp[64], r2 = hp[128];
-  bool run = remaining > 0 && hs > 0;
+  // the smallest BFU has 4 coefficients, so with fewer than 4 bits left no entry can take its next step: the
+  // remaining iterations of the reference only pop entries that do not fit and change nothing (:251-258)
+  bool run = remaining >= 4 && hs > 0;
   while (__builtin_amdgcn_ballot_w64(run) != 0) {
     const uint32_t top = r0;
     const int wl = (top >> 6) & 15, size = (top >> 16) & 31, s = (top >> 10) & 63;
@@ -137,7 +139,7 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
         heap_sift_down(hp, 52, i2, v, s2[0], s2[64], mv1);
       }
     }
-    run = run && remaining > 0 && hs > 0;
+    run = run && remaining >= 4 && hs > 0;
   }
   hp[0] = r0; hp[64] = r1; hp[128] = r2;
   // every BFU that ever entered the heap now sits in slots [0, hs0) with its final word length
