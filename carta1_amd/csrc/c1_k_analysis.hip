@@ -189,7 +189,11 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       }
       __syncthreads();
       float *coef = S.u.m.a.c.coef;
+      // the QMF phases saturate VALU and LDS together, the MDCT rounds are chains of dependent round trips: waves
+      // in the QMF get the issue slots first (measured: -3 % kernel time)
+      __builtin_amdgcn_s_setprio(0);
       mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT, EARLY);
+      __builtin_amdgcn_s_setprio(3);
       __syncthreads();
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
