@@ -117,6 +117,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
     __syncthreads();
     {
       double ev[4], od[4];
+      if constexpr (ALL_LONG) __builtin_amdgcn_s_setprio(3);
       if (own_block()) qmf_analysis_core<4, 3>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
       double *w2 = S.u.q2.w2;
       if (lane < 46) { w2[pidx<2>(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx<3>(512 + lane)]; }
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
     {
       double ev[2], od[2];
       if (own_block()) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
+      if constexpr (ALL_LONG) __builtin_amdgcn_s_setprio(1);
       *reinterpret_cast<float2 *>(&band_[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
       *reinterpret_cast<float2 *>(&band_[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
       *reinterpret_cast<float4 *>(&band_[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
@@ -189,11 +191,11 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       }
       __syncthreads();
       float *coef = S.u.m.a.c.coef;
-      // the QMF phases saturate VALU and LDS together, the MDCT rounds are chains of dependent round trips: waves
-      // in the QMF get the issue slots first (measured: -3 % kernel time)
+      // Wave priorities: the QMF cores saturate VALU and LDS together (3), the MDCT rounds are chains of dependent
+      // round trips that the other waves fill anyway (0), staging and output in between (1).  Measured: -4 %.
       __builtin_amdgcn_s_setprio(0);
       mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT, EARLY);
-      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_s_setprio(1);
       __syncthreads();
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
