@@ -153,6 +153,18 @@ __device__ __forceinline__ void qmf_synthesis_core(const double *w, int lane, Ta
   }
 }
 
+// inclusive prefix sum over the 64 lanes of a wave with data-parallel primitives (row shifts inside the rows of 16
+// lanes, then the row totals broadcast from lanes 15 and 31): 6 DPP adds, no LDS crossbar round trips
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 __device__ __forceinline__ int bitrev(int k, int log2n) { return (int)(__brev((unsigned)k) >> (32 - log2n)); }
 
 // findScaleFactor on binary32 bit patterns: with SF[3q] = 2^(q-21) and the two in-between fraction

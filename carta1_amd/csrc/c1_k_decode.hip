@@ -201,12 +201,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       sfi = (int)get_bits_be(S.words, 16 + 4 * n + 6 * lane, 6);
     }
     const int mybits = wl_bits(wl) * my_size;
-    int scan = mybits;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(scan, d);
-      if (lane >= d) scan += o;
-    }
+    const int scan = wave_inclusive_scan(mybits);
     if (lane < 52) S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
     __syncthreads();
     // ---------------- dequantizationStage (decoder.js:52-98) ----------------

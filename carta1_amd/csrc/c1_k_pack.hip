@@ -143,12 +143,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     // bit offset of every BFU's mantissas: exclusive prefix sum of bits*size over the wave
     const int bits_b = wl_bits(wl);
     const int mybits = bits_b * my_size;
-    int scan = mybits;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(scan, d);
-      if (lane >= d) scan += o;
-    }
+    const int scan = wave_inclusive_scan(mybits);
     if (lane < 52) {
       const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
       S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
