@@ -228,7 +228,9 @@ __device__ __forceinline__ void sf_long(const float *coef, uint8_t *sfi_out, con
   float mx = 0.0f;
 #pragma unroll
   for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < g.cnt ? j : g.cnt - 1]));
-  mx = fmaxf(mx, g.wide ? __shfl_xor(mx, 1) : 0.0f);
+  // the neighbour lane's maximum: a DPP quad permutation [1,0,3,2], not an LDS-crossbar shuffle
+  const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false));
+  mx = fmaxf(mx, g.wide ? other : 0.0f);
   const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
   if (g.store) sfi_out[g.b] = (uint8_t)sfi;
 }

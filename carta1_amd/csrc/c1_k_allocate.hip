@@ -231,16 +231,11 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
   }
   // append the surviving (unit, candidate) pairs to the work list: one atomic per wave
   const int mine = live ? __popc(survivors) : 0;
-  int scan = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(scan, d);
-    if (lane >= d) scan += o;
-  }
-  const int wave_total = __shfl(scan, 63);
+  const int scan = wave_inclusive_scan(mine);
+  const int wave_total = __builtin_amdgcn_readlane(scan, 63);
   uint32_t base_idx = 0;
   if (lane == 0 && wave_total > 0) base_idx = atomicAdd(L.work_count, (uint32_t)wave_total);
-  base_idx = __shfl(base_idx, 0);
+  base_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_idx);
   if (mine > 0) {
     uint32_t at = base_idx + (uint32_t)(scan - mine);
     for (int c = 0; c < 7; c++)

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_detect_decide(const double *__restrict_
     if (ml) base_l = atomicAdd(&lists[0], (uint32_t)__popcll(ml));
     if (mm) base_m = atomicAdd(&lists[1], (uint32_t)__popcll(mm));
   }
-  base_l = __shfl(base_l, 0); base_m = __shfl(base_m, 0);
+  base_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_l); base_m = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_m);
   if (is_long) list_long[base_l + __popcll(ml & below)] = (uint32_t)unit;
   if (is_mixed) list_mixed[base_m + __popcll(mm & below)] = (uint32_t)unit;
 }
