@@ -255,6 +255,66 @@ napi_value DecodeBatch(napi_env env, napi_callback_info info) {
   return arr;
 }
 
+// encodeWavBatch(ctx, Int16Array | Uint8Array wavBody, bits, channels, options) -> Uint8Array units
+// (c1_encode_wav_batch: interleaved little-endian integer PCM converted on the device, ragged tail zero padded)
+napi_value EncodeWavBatch(napi_env env, napi_callback_info info) {
+  napi_value argv[5];
+  if (!get_args(env, info, 5, argv)) return nullptr;
+  c1_ctx *ctx;
+  if (!get_external(env, argv[0], &ctx)) return nullptr;
+  bool is_ta = false;
+  NAPI_OK(napi_is_typedarray(env, argv[1], &is_ta));
+  if (!is_ta) { napi_throw_type_error(env, nullptr, "wav body must be an Int16Array or a Uint8Array"); return nullptr; }
+  napi_typedarray_type tt;
+  size_t len = 0, off = 0;
+  void *data = nullptr;
+  napi_value ab;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &tt, &len, &data, &ab, &off));
+  if (tt != napi_int16_array && tt != napi_uint8_array) { napi_throw_type_error(env, nullptr, "wav body must be an Int16Array or a Uint8Array"); return nullptr; }
+  const size_t bytes = tt == napi_int16_array ? len * 2 : len;
+  int32_t bits = 16, channels = 1;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &bits));
+  NAPI_OK(napi_get_value_int32(env, argv[3], &channels));
+  c1_encode_options o;
+  if (!get_options(env, argv[4], &o)) return nullptr;
+  if ((bits != 16 && bits != 24 && bits != 32) || channels < 1 || channels > 2 || bytes % ((size_t)channels * (bits / 8))) {
+    napi_throw_type_error(env, nullptr, "wav body: bits must be 16, 24 or 32, channels 1 or 2, and the length a whole number of samples");
+    return nullptr;
+  }
+  const int64_t samples = (int64_t)(bytes / ((size_t)channels * (bits / 8)));
+  const int64_t frames = (samples + 511) / 512;
+  uint8_t *units;
+  napi_value out = make_u8(env, (size_t)frames * channels * C1_UNIT_BYTES, &units);
+  if (!out) { napi_throw_error(env, nullptr, "allocation failed"); return nullptr; }
+  const int rc = c1_encode_wav_batch(ctx, data, bits, channels, samples, &o, units);
+  if (rc) return throw_c1(env, rc);
+  return out;
+}
+
+// decodeWav16Batch(ctx, Uint8Array units, channels) -> Int16Array (interleaved, frames * 512 * channels)
+napi_value DecodeWav16Batch(napi_env env, napi_callback_info info) {
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  c1_ctx *ctx;
+  void *d;
+  size_t n;
+  int32_t channels = 1;
+  if (!get_external(env, argv[0], &ctx) || !get_typed(env, argv[1], napi_uint8_array, &d, &n)) return nullptr;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &channels));
+  if (channels < 1 || channels > 2 || n % ((size_t)channels * C1_UNIT_BYTES)) { napi_throw_type_error(env, nullptr, "units: wrong length"); return nullptr; }
+  const int64_t frames = (int64_t)(n / ((size_t)channels * C1_UNIT_BYTES));
+  const size_t count = (size_t)frames * 512 * channels;
+  napi_value ab, ta;
+  void *p;
+  if (!make_buffer(env, count * 2, count * 2 > kPinnedThreshold, &p, &ab) || napi_create_typedarray(env, napi_int16_array, count, ab, 0, &ta) != napi_ok) {
+    napi_throw_error(env, nullptr, "allocation failed");
+    return nullptr;
+  }
+  const int rc = c1_decode_wav16_batch(ctx, static_cast<const uint8_t *>(d), channels, frames, static_cast<int16_t *>(p));
+  if (rc) return throw_c1(env, rc);
+  return ta;
+}
+
 // ---- asynchronous batches: the typed arrays are kept alive by references while the work runs ----------
 struct AsyncJob {
   napi_async_work work = nullptr;
@@ -455,6 +515,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"allocPinned", nullptr, AllocPinned, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"encodeBatch", nullptr, EncodeBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"decodeBatch", nullptr, DecodeBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"encodeWavBatch", nullptr, EncodeWavBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"decodeWav16Batch", nullptr, DecodeWav16Batch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"encodeBatchAsync", nullptr, EncodeBatchAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"decodeBatchAsync", nullptr, DecodeBatchAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"encStreamCreate", nullptr, EncStreamCreate, nullptr, nullptr, nullptr, napi_default, nullptr},

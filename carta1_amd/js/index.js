@@ -6,7 +6,7 @@
 export { encode } from './pipeline/encoder.js'
 export { decode } from './pipeline/decoder.js'
 export { serializeFrame, deserializeFrame, AeaFile } from './io/serialization.js'
-export { AudioProcessor, encodeAeaPcm, decodeAeaPcm } from './io/processor.js'
+export { AudioProcessor, encodeAeaPcm, decodeAeaPcm, encodeWavPcm, decodeAeaToWav16 } from './io/processor.js'
 export { BufferPool } from './core/buffers.js'
 export { EncoderOptions } from './core/options.js'
 export { pipe } from './utils.js'

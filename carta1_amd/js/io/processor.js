@@ -63,6 +63,34 @@ export async function decodeAeaPcm(input) {
   return native().decodeBatchAsync(context(), body, nch, 0)
 }
 
+// WAV body (interleaved little-endian integer PCM: Int16Array, or a Uint8Array with bits = 16, 24 or 32) -> AEA image.
+// What the reference's CLI does with WavReader + encodeStream (bin/cli.js:367-404, processor.js:246-276) as one
+// native call: the integer samples cross PCIe and are converted on the device.
+export function encodeWavPcm(wavBody, options = {}) {
+  const { title = 'encoded by carta1', channelCount = 1, bits = 16, ...encoderValues } = options
+  if (!(wavBody instanceof Int16Array) && !(wavBody instanceof Uint8Array)) {
+    throw new TypeError('ATRAC1 WAV encoding requires an Int16Array or a Uint8Array of sample bytes')
+  }
+  if (channelCount !== 1 && channelCount !== 2) throw new TypeError('ATRAC1 encoding requires one or two channels')
+  const encoderOptions = new EncoderOptions(encoderValues)
+  const units = native().encodeWavBatch(context(), wavBody, wavBody instanceof Int16Array ? 16 : bits, channelCount, encoderOptions.toNative())
+  const image = new Uint8Array(AEA_HEADER_SIZE + units.length)
+  image.set(AeaFile.createHeader(title, units.length / SOUND_UNIT_SIZE, channelCount), 0)
+  image.set(units, AEA_HEADER_SIZE)
+  return image
+}
+
+// AEA image -> { channelCount, samples: Int16Array (interleaved) }: decode + the 16-bit conversion of createWavBlob
+// (processor.js:349-447) on the device
+export function decodeAeaToWav16(bytes) {
+  if (!(bytes instanceof Uint8Array)) throw new TypeError('ATRAC1 decoding requires AEA bytes')
+  const { info, units } = AudioProcessor.parseAea(bytes)
+  const nch = info.channelCount
+  if (nch !== 1 && nch !== 2) throw new Error(`Unsupported channel count: ${nch}`)
+  const whole = units.subarray(0, units.length - (units.length % (nch * SOUND_UNIT_SIZE)))
+  return { channelCount: nch, samples: whole.length ? native().decodeWav16Batch(context(), whole, nch) : new Int16Array(0) }
+}
+
 export class AudioProcessor {
   static encodeAeaPcm(channels, options = {}) { return encodeAeaPcm(channels, options) }
   static decodeAeaPcm(input) { return decodeAeaPcm(input) }

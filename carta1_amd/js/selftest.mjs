@@ -117,6 +117,30 @@ async function main() {
     const frames = c1.AudioProcessor.frameBufferToFrames([white(11, 700), white(12, 700)])
     const fieldsList = await c1.AudioProcessor.collectFrames(c1.AudioProcessor.encodeStream(frames, { channelCount: 2 }))
     ok(fieldsList.length === 4 && hex(await c1.AudioProcessor.createAeaBytes(fieldsList, { title: 'encoded by carta1', channelCount: 2 })) === hex(img), 'AudioProcessor.encodeStream == encodeAeaPcm')
+    // 16-bit WAV body in one native call == float conversion (value / 32768, bin/cli.js:394-404) + encodeAeaPcm
+    {
+      const ns = 700, wav = new Int16Array(ns * 2)
+      const l = new Float32Array(ns), r = new Float32Array(ns)
+      const a = white(31, ns), b = white(32, ns)
+      for (let i = 0; i < ns; i++) {
+        wav[2 * i] = Math.round(a[i] * 40000); wav[2 * i + 1] = Math.round(b[i] * 40000)
+        l[i] = wav[2 * i] / 32768; r[i] = wav[2 * i + 1] / 32768
+      }
+      const viaFloat = await c1.encodeAeaPcm([l, r], {})
+      const viaWav = c1.encodeWavPcm(wav, { channelCount: 2 })
+      ok(hex(viaFloat) === hex(viaWav), 'encodeWavPcm(Int16Array) == encodeAeaPcm(float conversion)')
+      const back = c1.decodeAeaToWav16(viaWav)
+      const pcm = await c1.decodeAeaPcm(viaWav)
+      let same = back.channelCount === 2 && back.samples.length === pcm[0].length * 2
+      for (let i = 0; same && i < pcm[0].length; i++) {
+        for (let c = 0; c < 2; c++) {
+          const x = Math.max(-1, Math.min(1, pcm[c][i]))
+          const want = (x < 0 ? x * 0x8000 : x * 0x7fff) | 0
+          if (back.samples[2 * i + c] !== want) same = false
+        }
+      }
+      ok(same, 'decodeAeaToWav16 == decodeAeaPcm + the 16-bit conversion of createWavBlob')
+    }
     // page-locked PCM: a batch of more than one streaming chunk (32768 frames) must give the same bytes
     {
       const nf = 40000, plain = white(21, nf * 512)
