@@ -136,6 +136,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
     __syncthreads();
     {
       double ev[4], od[4];
+      __builtin_amdgcn_s_setprio(3);   // wave priorities as in k_analysis_fast: QMF cores 3, transient FFT 0, the rest 1
       if (own_block()) qmf_analysis_core<4, 3>(S.u.q1.w1, lane, T, ev, od); else { for (int d = 0; d < 4; d++) { ev[d] = S.u.q1.w1[lane + d]; od[d] = 1.0; } }
       double *w2 = S.u.q2.w2;
       if (lane < 46) { w2[pidx<2>(lane)] = S.d2[lane]; S.d1[lane] = S.u.q1.w1[pidx<3>(512 + lane)]; }
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
     {
       double ev[2], od[2];
       if (own_block()) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
+      __builtin_amdgcn_s_setprio(1);
       *reinterpret_cast<float2 *>(&S.band[2 * lane]) = make_float2(f32(ev[0] + od[0]), f32(ev[1] + od[1]));
       *reinterpret_cast<float2 *>(&S.band[128 + 2 * lane]) = make_float2(f32(ev[0] - od[0]), f32(ev[1] - od[1]));
       *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
     const double2 w8 = table_pair(RT, t_twb), w16a = table_pair(RT, t_twb + 128), w16b = table_pair(RT, t_twb + 256);
     const double2 w32a = table_pair(RT, t_twb + 384), w32b = table_pair(RT, t_twb + 512);
     const double2 w32c = table_pair(RT, t_twb + 640), w32d = table_pair(RT, t_twb + 768);
+    __builtin_amdgcn_s_setprio(0);
     tfft_round_a(x, T);
     float2 *z = S.u.t.z;
     {
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) pmag[i] = mg[i];
+    __builtin_amdgcn_s_setprio(1);
     __syncthreads();
   }
 }
