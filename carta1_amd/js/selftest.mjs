@@ -117,6 +117,13 @@ async function main() {
     const frames = c1.AudioProcessor.frameBufferToFrames([white(11, 700), white(12, 700)])
     const fieldsList = await c1.AudioProcessor.collectFrames(c1.AudioProcessor.encodeStream(frames, { channelCount: 2 }))
     ok(fieldsList.length === 4 && hex(await c1.AudioProcessor.createAeaBytes(fieldsList, { title: 'encoded by carta1', channelCount: 2 })) === hex(img), 'AudioProcessor.encodeStream == encodeAeaPcm')
+    // batched stream encoding: same frame fields as the per-frame closures
+    {
+      const src = [pinkT(3, 100 * 512), pinkT(4, 100 * 512)]
+      const one = await c1.AudioProcessor.collectFrames(c1.AudioProcessor.encodeStream(c1.AudioProcessor.frameBufferToFrames(src), { channelCount: 2 }))
+      const many = await c1.AudioProcessor.collectFrames(c1.AudioProcessor.encodeStream(c1.AudioProcessor.frameBufferToFrames(src), { channelCount: 2, batchFrames: 37 }))
+      ok(one.length === 200 && many.length === 200 && one.every((f, i) => hex(c1.serializeFrame(f)) === hex(c1.serializeFrame(many[i]))), 'encodeStream with batchFrames 37 == per-frame closures')
+    }
     // 16-bit WAV body in one native call == float conversion (value / 32768, bin/cli.js:394-404) + encodeAeaPcm
     {
       const ns = 700, wav = new Int16Array(ns * 2)
