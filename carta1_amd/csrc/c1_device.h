@@ -213,16 +213,20 @@ struct FrameModes {
 // combined.  The lane's slice is fixed, so it is looked up once per wave (a lookup inside the frame loop is a
 // global load whose wait also waits for the frame's stores).
 struct SfLong { int cnt, src, b; bool wide, store; };
-__device__ __forceinline__ SfLong sf_long_geometry(int lane) {
+// mode_of_band: block mode of bands 0..2 (0 = long); BFU b starts at kStartLong[b] or kStartShort[b] accordingly
+__device__ __forceinline__ SfLong sf_geometry(int lane, int m0, int m1, int m2) {
   SfLong g;
   g.wide = lane >= 44;
   g.b = g.wide ? 44 + ((lane - 44) >> 1) : lane;
   const int half = g.wide ? (lane & 1) : 0;
   g.cnt = lane < 60 ? (g.wide ? 10 : (int)kSpecs[lane < 44 ? lane : 0]) : 1;
-  g.src = kStartLong[lane < 60 ? g.b : 0] + 10 * half;
+  const int bb = lane < 60 ? g.b : 0;
+  const int mode = bb >= 36 ? m2 : (bb >= 20 ? m1 : m0);
+  g.src = (mode == 0 ? kStartLong[bb] : kStartShort[bb]) + 10 * half;
   g.store = lane < 60 && (!g.wide || half == 0);
   return g;
 }
+__device__ __forceinline__ SfLong sf_long_geometry(int lane) { return sf_geometry(lane, 0, 0, 0); }
 __device__ __forceinline__ void sf_long(const float *coef, uint8_t *sfi_out, const SfLong &g, TablesPtr T) {
   const float *src = coef + g.src;
   float mx = 0.0f;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   // lane-only geometry of the long-block MDCT core, computed once (everything else is re-derived per frame)
   const R4Geometry G4 = r4_geometry(lane0);
   const SfLong SFL = sf_long_geometry(lane0);
-  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
+  const SfLong SFM = sf_geometry(lane0, O->modes[0], O->modes[1], O->modes[2]);     // used when !ALL_LONG
   const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
@@ -237,15 +237,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
         dst[lane] = src[lane];
         dst[64 + lane] = src[64 + lane];
       }
-      if (lane < 52) {
-        const int start = M.mode_of_band(band_of_bfu(lane)) == 0 ? my_long : my_short;
-        const int n = my_size;
-        float mx = 0.0f;
-        for (int j = 0; j < n; j++) mx = fmaxf(mx, fabsf(coef[start + j]));
-        S.sfi[lane] = (uint8_t)(T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T));
-      } else {
-        S.sfi[lane] = lane == 52 ? (uint8_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0;
-      }
+      sf_long(coef, S.sfi, SFM, T);                       // same 12-read scheme, BFU starts of the fixed modes
+      if (lane >= 60 && lane < 63) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60)] = lane == 60 ? (uint32_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0u;
       __syncthreads();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
       __syncthreads();
