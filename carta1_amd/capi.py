@@ -48,6 +48,8 @@ SIGNATURES = {
     'c1_ctx_synchronize': (C.c_int, [C.c_void_p]),
     'c1_ctx_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'c1_ctx_kernel_ms': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'c1_ctx_set_speculation': (C.c_int, [C.c_void_p, C.c_int]),
+    'c1_ctx_speculation_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     'c1_encode_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                    C.POINTER(EncodeOptions), C.c_void_p]),
     'c1_encode_batch': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
@@ -72,6 +74,8 @@ SIGNATURES = {
     'c1_encode_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                           C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    'c1_spec_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
+                                        C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -72,8 +72,10 @@ class EncoderOptions:
                 o.biased_scale_factors[i] = math.pow(sf[i], bias)
         o.transient_threshold = float(self.values['transientThresholdLow'])   # encoder.js:137-141
         fm = self.values['fixedBlockModes']
+        if fm is not None and len(fm) != 3:
+            raise ValueError('fixedBlockModes must have 3 entries, got %d' % len(fm))
         for b in range(3):
-            o.fixed_block_modes[b] = int(fm[b]) if fm else -1
+            o.fixed_block_modes[b] = int(fm[b]) if fm is not None else -1
         return o
 
 
@@ -106,6 +108,16 @@ class Context:
         ms, n = C.c_double(0), C.c_int(0)
         capi.check(capi.load().c1_ctx_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_speculation(self, mode):
+        """0 = exact kernels only, 1 = adaptive (default), 2 = always speculate (include/carta1_hip.h)."""
+        capi.check(capi.load().c1_ctx_set_speculation(self._h, int(mode)))
+
+    def speculation_stats(self, reset=False):
+        """(units encoded through the speculative pass, units among them redone by the exact kernels)."""
+        u, r = C.c_uint64(0), C.c_uint64(0)
+        capi.check(capi.load().c1_ctx_speculation_stats(self._h, C.byref(u), C.byref(r), 1 if reset else 0))
+        return u.value, r.value
 
     # ---- host-resident batches ------------------------------------------------------------------
     def encode(self, channels, options=None, halo_frames=0, out=None):
@@ -193,6 +205,13 @@ class Context:
         capi.check(capi.load().c1_encode_stages_device(
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
             C.c_void_p(bands_ptr), C.c_void_p(coefs_ptr), C.c_void_p(side_ptr), C.c_void_p(alloc_ptr)))
+
+    def spec_stages_device(self, pcm_ptrs, frames, coefs_ptr, eps_ptr, side_ptr, options=None, halo_frames=0):
+        """The speculative binary32 analysis alone: coefficients, their proven error bounds, scale-factor indices."""
+        opts = (options or EncoderOptions({'fixedBlockModes': [0, 0, 0]})).to_c()
+        capi.check(capi.load().c1_spec_stages_device(
+            self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
+            C.c_void_p(coefs_ptr), C.c_void_p(eps_ptr), C.c_void_p(side_ptr)))
 
 
 class EncoderStream:

@@ -72,6 +72,82 @@ void qmf_even_taps(double out[24]) {
   for (int j = 0; j < 24; j++) out[j] = (double)window[2 * j];
 }
 
+// ---- speculative binary32 path (c1_k_spec.hip): rounded tables and the coefficients of its error bound -------------
+// DESIGN.md 3b derives   eps_b = u (1 + theta) [ KA_b sigma sqrt(n_b) Z_b + sigma^2 sqrt(2 n_b) (D_b + 3 T_b) ] + eabs
+// with u = 2^-24, Z_b the measured norm of the band's pre-twiddled points, W / L the measured norms of the PCM and of
+// the first-stage low band over the two frames a unit depends on, and
+//   D_2 = (2 gH + gQ) W,  T_2 = gH W;   D_0 = D_1 = gH (2 L + gQ W) + (2 gH + gQ) L,  T_0 = T_1 = gH L.
+// gH bounds the l2 gain of one QMF branch (sqrt(|E|^2 + |O|^2) of the polyphase responses), gQ the accumulated
+// rounding of the two-chain binary32 convolution in units of u * |input|; both depend only on the QMF prototype, which
+// is compiled in (tools/spec_constants.py recomputes them from the taps; tests/test_spec_bound.py checks these are >=).
+constexpr double kSpecGH = 1.4160, kSpecGQ = 4.80;
+// KA = post-twiddle (1 + 2 sqrt 2) + 1  |  FFT rounds  |  pre-twiddle (1 + 3 sqrt 2) + 1      (reference's share + ours)
+constexpr double kSpecKAPost = 4.83, kSpecKAPre = 6.25;
+constexpr double kSpecKARoundA = 4.0, kSpecKARound4 = 7.0, kSpecKARound2 = 5.0;
+constexpr double kSpecTheta = 1.01;
+float round_up_f32(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+void build_spec_tables(const c1_tables &t, C1DevTables *d) {
+  for (int j = 0; j < 24; j++) d->tap32[j] = (float)d->tap_e[j];
+  bool ok = d->sf_fast != 0;
+  for (int i = 0; i < 32; i++) {
+    d->win32[i] = (float)t.window_short[i];
+    if (!(t.window_short[i] >= 0.0 && t.window_short[i] <= 1.0)) ok = false;
+  }
+  for (int i = 0; i < 16; i++) { d->pre32_64[i][0] = (float)t.mdct_fwd64[2 * i]; d->pre32_64[i][1] = (float)t.mdct_fwd64[2 * i + 1]; }
+  for (int i = 0; i < 64; i++) { d->pre32_256[i][0] = (float)t.mdct_fwd256[2 * i]; d->pre32_256[i][1] = (float)t.mdct_fwd256[2 * i + 1]; }
+  for (int i = 0; i < 128; i++) { d->pre32_512[i][0] = (float)t.mdct_fwd512[2 * i]; d->pre32_512[i][1] = (float)t.mdct_fwd512[2 * i + 1]; }
+  // every (cos, sin) pair of an MDCT table has the same modulus sigma = sqrt(scale / N) (mdct.js:27-36)
+  auto sigma2 = [&](const double *tab, int pairs, double want) {
+    double mx = 0;
+    for (int i = 0; i < pairs; i++) {
+      const double m = tab[2 * i] * tab[2 * i] + tab[2 * i + 1] * tab[2 * i + 1];
+      if (!(std::fabs(m - want) <= 1e-9 * want)) ok = false;
+      mx = std::max(mx, m);
+    }
+    return mx;
+  };
+  const double s64 = sigma2(t.mdct_fwd64, 16, 0.5 / 64), s256 = sigma2(t.mdct_fwd256, 64, 0.5 / 256), s512 = sigma2(t.mdct_fwd512, 128, 1.0 / 512);
+  // the FFT twiddles must be the unit-modulus roots the radix-4 regrouping assumes (to 1e-12; the bound's theta absorbs that)
+  const double (*tw)[2] = d->fft_tw;
+  for (int h = 1; h <= 128; h <<= 1)
+    for (int k = 0; k < h; k++) {
+      const double ang = -M_PI * (double)k / (double)h;
+      if (std::fabs(tw[h - 1 + k][0] - std::cos(ang)) > 1e-12 || std::fabs(tw[h - 1 + k][1] - std::sin(ang)) > 1e-12) ok = false;
+    }
+  for (int r = 0; r < 2; r++) {
+    const int h = r == 0 ? 4 : 16;
+    for (int k = 0; k < h; k++) {
+      const double *a = tw[h - 1 + k], *b = tw[2 * h - 1 + k];
+      float (*dst)[2] = r == 0 ? d->r4b[k] : d->r4c[k];
+      dst[0][0] = (float)a[0]; dst[0][1] = (float)a[1];
+      dst[1][0] = (float)b[0]; dst[1][1] = (float)b[1];
+      dst[2][0] = (float)(a[0] * b[0] - a[1] * b[1]);
+      dst[2][1] = (float)(a[0] * b[1] + a[1] * b[0]);
+    }
+  }
+  for (int k = 0; k < 64; k++) { d->r2d[k][0] = (float)tw[63 + k][0]; d->r2d[k][1] = (float)tw[63 + k][1]; }
+  for (int i = 0; i < 64 * 16; i++) d->norm32[i] = (float)d->norm[i];
+  const double u = std::ldexp(1.0, -24) * kSpecTheta;
+  const double ka64 = kSpecKAPost + kSpecKARoundA + 2 * kSpecKARound4 + kSpecKAPre;
+  const double ka128 = ka64 + kSpecKARound2;
+  const double ka16 = kSpecKAPost + kSpecKARoundA + kSpecKARound4 + kSpecKAPre;
+  for (int b = 0; b < 3; b++) {
+    const double n = b == 2 ? 128 : 64, sg2 = b == 2 ? s512 : s256;
+    d->spec_cz[b] = round_up_f32(u * (b == 2 ? ka128 : ka64) * std::sqrt(sg2 * n));
+    const double gb = u * sg2 * std::sqrt(2 * n);
+    if (b == 2) { d->spec_cw[b] = round_up_f32(gb * (5 * kSpecGH + kSpecGQ)); d->spec_cl[b] = 0.0f; }
+    else { d->spec_cw[b] = round_up_f32(gb * kSpecGH * kSpecGQ); d->spec_cl[b] = round_up_f32(gb * (7 * kSpecGH + kSpecGQ)); }
+    d->spec_cz_short[b] = round_up_f32(u * ka16 * std::sqrt(s64 * 16));
+  }
+  d->spec_cz[3] = d->spec_cw[3] = d->spec_cl[3] = d->spec_cz_short[3] = 0.0f;
+  d->spec_eabs = (float)std::ldexp(1.0, -70);
+  d->spec_ok = ok ? 1 : 0;
+}
+
 void build_device_tables(const c1_tables &t, C1DevTables *d) {
   memset(d, 0, sizeof *d);
   qmf_even_taps(d->tap_e);
@@ -142,6 +218,7 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
       }
     }
   }
+  build_spec_tables(t, d);
 }
 
 // rank table of the Float32 heap priorities (bitallocation.js:226-231, 267-269)
@@ -211,8 +288,8 @@ struct Timing {
   hipEvent_t start, stop;
   int kind;
 };
-enum { K_ANALYSIS = 0, K_ALLOCATE, K_PACK, K_DECODE, K_KINDS };
-const char *const kKindNames[K_KINDS] = {"analysis", "allocate", "pack", "decode"};
+enum { K_ANALYSIS = 0, K_ALLOCATE, K_PACK, K_DECODE, K_REDO, K_KINDS };
+const char *const kKindNames[K_KINDS] = {"analysis", "allocate", "pack", "decode", "redo"};
 
 }  // namespace
 
@@ -231,6 +308,15 @@ struct c1_ctx {
   uint8_t *d_alloc[2] = {nullptr, nullptr};
   uint8_t *d_cand[2] = {nullptr, nullptr};
   uint32_t *d_work[2] = {nullptr, nullptr};      // [0] = count, list from [4]
+  // speculative binary32 path: per-unit error bounds, redo list ([0] = count, list from [4]), running totals
+  float *d_eps[2] = {nullptr, nullptr};
+  uint32_t *d_redo[2] = {nullptr, nullptr};
+  unsigned long long *d_spec_totals = nullptr;   // [0] units encoded speculatively, [1] units redone exactly
+  int spec_mode = 1;                             // 0 exact only, 1 adaptive (default), 2 always speculate
+  bool spec_tables_ok = false;
+  double spec_last_fraction = 0.0;               // redo fraction seen by the previous speculative call (adaptive mode)
+  int spec_exact_calls = 0;                      // calls sent down the exact path since that observation
+  unsigned long long spec_seen[2] = {0, 0};      // totals at the last observation
   // transient-detection workspace (allocated on first use): band samples, feature sums, block modes
   int64_t det_units = 0;
   float *d_bands[2] = {nullptr, nullptr};
@@ -245,8 +331,8 @@ struct c1_ctx {
   bool profiling = false;
   std::vector<Timing> timings;
   std::vector<hipEvent_t> event_pool;
-  double ms[K_KINDS] = {0, 0, 0, 0};
-  int launches[K_KINDS] = {0, 0, 0, 0};
+  double ms[K_KINDS] = {0, 0, 0, 0, 0};
+  int launches[K_KINDS] = {0, 0, 0, 0, 0};
   // scratch for host-resident calls
   void *d_io = nullptr;
   size_t d_io_bytes = 0;
@@ -272,7 +358,10 @@ void free_workspace(c1_ctx *ctx) {
     if (ctx->d_alloc[p]) (void)hipFree(ctx->d_alloc[p]);
     if (ctx->d_cand[p]) (void)hipFree(ctx->d_cand[p]);
     if (ctx->d_work[p]) (void)hipFree(ctx->d_work[p]);
+    if (ctx->d_eps[p]) (void)hipFree(ctx->d_eps[p]);
+    if (ctx->d_redo[p]) (void)hipFree(ctx->d_redo[p]);
     ctx->d_coefs[p] = nullptr; ctx->d_side[p] = nullptr; ctx->d_alloc[p] = nullptr; ctx->d_cand[p] = nullptr; ctx->d_work[p] = nullptr;
+    ctx->d_eps[p] = nullptr; ctx->d_redo[p] = nullptr;
   }
   ctx->ws_units = 0;
   for (int p = 0; p < 2; p++) {
@@ -314,6 +403,8 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
     HIP_TRY(hipMalloc(&ctx->d_alloc[p], (size_t)units * kAllocBytes));
     HIP_TRY(hipMalloc(&ctx->d_cand[p], (size_t)units * kCandidateBytes));
     HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 7 + 4) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_eps[p], (size_t)units * kEpsFloats * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units + 4) * sizeof(uint32_t)));
   }
   ctx->ws_units = units;
   return C1_OK;
@@ -420,7 +511,23 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   // Two-stage software pipeline over chunks: the analysis of chunk i+1 (fp64-VALU bound) runs on one
   // stream while allocation + packing of chunk i (latency bound) run on another, each chunk on its own
   // half of the workspace.  Everything is ordered after the caller's stream and joined back into it.
-  const bool piped = ctx->pipeline && !taps && frames > chunk;
+  const bool all_long_modes = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&
+                              opts->fixed_block_modes[2] == 0 && !getenv("C1_NO_FAST_LONG");
+  bool speculate = all_long_modes && !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;
+  if (speculate && ctx->spec_mode == 1) {
+    // adaptive: look at what the previous speculative call had to redo (its kernels have normally finished by now).
+    // Signals whose spectrum is far from flat (tones) fail the guard band for most units; then the speculative pass
+    // is wasted work, so such streams go straight to the exact kernels, with a fresh probe every 16th call.
+    unsigned long long tot[2];
+    if (hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess) {
+      const unsigned long long du = tot[0] - ctx->spec_seen[0], dr = tot[1] - ctx->spec_seen[1];
+      if (du > 0) { ctx->spec_last_fraction = (double)dr / (double)du; ctx->spec_exact_calls = 0; }
+      ctx->spec_seen[0] = tot[0]; ctx->spec_seen[1] = tot[1];
+    }
+    if (ctx->spec_last_fraction > 0.30 && ctx->spec_exact_calls < 15) { speculate = false; ctx->spec_exact_calls++; }
+  }
+  const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate;
   hipStream_t sA = piped ? ctx->s_ana : ctx->stream, sB = piped ? ctx->s_rest : ctx->stream;
   if (piped) {
     HIP_TRY(hipEventRecord(ctx->ev_in, ctx->stream));
@@ -447,9 +554,31 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.work_list = ctx->d_work[p] + 4;
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
-    const bool all_long = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&
-                          opts->fixed_block_modes[2] == 0 && !getenv("C1_NO_FAST_LONG");
+    const bool all_long = all_long_modes;
     if (piped && index >= 2) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_free[p], 0));   // workspace half p is free again
+    if (speculate) {
+      // Speculative pass in binary32 (c1_k_spec.hip): coefficients with a proven error bound; allocation works on the
+      // scale-factor indices; the packing kernel accepts a unit only when every decision is certain within the bound
+      // and lists the others.  Then the exact kernels redo the listed units in place.
+      L.eps = ctx->d_eps[p];
+      L.redo_count = ctx->d_redo[p];
+      L.redo_list = ctx->d_redo[p] + 4;
+      HIP_TRY(hipMemsetAsync(L.redo_count, 0, sizeof(uint32_t), sA));
+      { ScopedTiming t(ctx, K_ANALYSIS, sA); c1k_launch_analysis_spec(L, sA); }
+      { ScopedTiming t(ctx, K_ALLOCATE, sA); c1k_launch_allocate(L, sA); }
+      { ScopedTiming t(ctx, K_PACK, sA); c1k_launch_pack_spec(L, sA); }
+      {
+        ScopedTiming t(ctx, K_REDO, sA);
+        C1EncodeLaunch R = L;
+        R.unit_list = L.redo_list;
+        R.unit_count = L.redo_count;
+        c1k_launch_analysis_long(R, sA);
+        c1k_launch_allocate(R, sA);
+        c1k_launch_pack(R, true, sA);
+        c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), L.redo_count, sA);
+      }
+      continue;
+    }
     {
       ScopedTiming t(ctx, K_ANALYSIS, sA);
       if (all_long) c1k_launch_analysis_long(L, sA);
@@ -592,6 +721,14 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   hipError_t me = hipMalloc(&ctx->d_tables, sizeof(C1DevTables));
   if (me == hipSuccess) me = hipMalloc(&ctx->d_opts, sizeof(C1DevEncOpts));
   if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
+  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, 2 * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, 2 * sizeof(unsigned long long));
+  ctx->spec_tables_ok = h->spec_ok != 0;
+  {
+    const char *sp = getenv("C1_SPEC");       // 0 exact only, 1 adaptive (default), 2 always speculate
+    ctx->spec_mode = sp ? atoi(sp) : 1;
+    if (ctx->spec_mode < 0 || ctx->spec_mode > 2) ctx->spec_mode = 1;
+  }
   delete h;
   if (me != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "table upload: %s", hipGetErrorString(me)); }
   {
@@ -622,6 +759,7 @@ int c1_ctx_destroy(c1_ctx *ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->d_tables) hipFree(ctx->d_tables);
   if (ctx->d_opts) hipFree(ctx->d_opts);
+  if (ctx->d_spec_totals) hipFree(ctx->d_spec_totals);
   (void)hipDeviceSynchronize();
   free_workspace(ctx);
   if (ctx->s_ana) (void)hipStreamDestroy(ctx->s_ana);
@@ -659,6 +797,30 @@ int c1_ctx_set_profiling(c1_ctx *ctx, int enabled) {
   return C1_OK;
 }
 
+int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
+  if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
+  if (mode < 0 || mode > 2) return fail(C1_ERR_ARG, "speculation mode must be 0, 1 or 2, got %d", mode);
+  ctx->spec_mode = mode;
+  ctx->spec_last_fraction = 0.0;
+  ctx->spec_exact_calls = 0;
+  return C1_OK;
+}
+
+int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  unsigned long long tot[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (units) *units = tot[0];
+  if (redone) *redone = tot[1];
+  if (reset) {
+    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, sizeof tot, ctx->stream));
+    ctx->spec_seen[0] = ctx->spec_seen[1] = 0;
+  }
+  return C1_OK;
+}
+
 int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches) {
   int rc = ctx_bind(ctx);
   if (rc) return rc;
@@ -693,6 +855,31 @@ int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
                             const c1_encode_options *opts, float *bands, float *coefs, uint8_t *side,
                             uint8_t *alloc) {
   return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, nullptr, bands, coefs, side, alloc);
+}
+
+int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                          const c1_encode_options *opts, float *coefs, float *eps, uint8_t *side) {
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
+  if (!pcm || !opts || !coefs || !eps || !side) return fail(C1_ERR_ARG, "NULL argument");
+  if (opts->fixed_block_modes[0] != 0 || opts->fixed_block_modes[1] != 0 || opts->fixed_block_modes[2] != 0)
+    return fail(C1_ERR_ARG, "the speculative analysis covers fixed block modes [0,0,0] only");
+  if (!ctx->spec_tables_ok) return fail(C1_ERR_STATE, "the installed tables fail the checks the error bound relies on");
+  for (int c = 0; c < channels; c++)
+    if (!pcm[c] || ((uintptr_t)pcm[c] & 15)) return fail(C1_ERR_ARG, "pcm[%d] must be a 16-byte aligned device pointer", c);
+  if ((rc = upload_opts(ctx, opts))) return rc;
+  if (frames == 0) return C1_OK;
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c];
+  L.channels = channels; L.frames = frames; L.halo_frames = halo_frames;
+  L.tables = ctx->d_tables; L.opts = ctx->d_opts;
+  L.coefs = coefs; L.eps = eps; L.side = side;
+  c1k_launch_analysis_spec(L, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
 }
 
 // ---- streamed host path --------------------------------------------------------------------------------------

@@ -31,6 +31,21 @@ struct C1DevTables {
   // the installed table (8.3 M cases), else the kernel divides
   int32_t dq_fast;
   double inv_range[16];      // RN(1 / (2^(wl) - 1)) by word-length index wl = 1..15
+  // ---- binary32 tables of the speculative path (c1_k_spec.hip): roundings of the tables above ----
+  float tap32[24];           // QMF_EVEN (binary32 in the reference already)
+  float win32[32];           // fl32(WINDOW_SHORT)
+  float pre32_64[16][2];     // fl32 of the MDCT (cos, sin) pairs
+  float pre32_256[64][2];
+  float pre32_512[128][2];
+  float r4b[4][3][2];        // radix-4 round over stages 4, 8:  k -> wa = tw[3+k], wb = tw[7+k], fl32(wa*wb)
+  float r4c[16][3][2];       // radix-4 round over stages 16, 32: k -> wa = tw[15+k], wb = tw[31+k], fl32(wa*wb)
+  float r2d[64][2];          // stage 64: fl32(tw[63+k])
+  float norm32[64 * 16];     // fl32(norm)
+  // error-bound coefficients per band (rounded up): eps_b = cz*Z_b + cw*W + cl*L + eabs
+  float spec_cz[4], spec_cw[4], spec_cl[4];
+  float spec_cz_short[4];    // cz when the band is coded with short blocks
+  float spec_eabs;
+  int32_t spec_ok;           // 0: the installed tables fail the structural checks the bound relies on -> exact path only
 };
 
 // ---- per-call encoder options in device form ---------------------------------------------------
@@ -53,6 +68,7 @@ constexpr int kRunFramesLong = 64;   // same, in the all-long-blocks fast path
 constexpr int kSideBytes = 64;   // per unit: sfi[52], modes byte, pad
 constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallback flag
 constexpr int kCandidateBytes = 8 * 8 + 8 * 32;  // per unit: 8 totals + 8 results (bit allocation scratch)
+constexpr int kEpsFloats = 4;    // per unit (speculative path): error bound of bands 0..2, flags
 
 struct C1EncodeLaunch {
   const float *pcm[C1_MAX_CHANNELS];
@@ -69,6 +85,13 @@ struct C1EncodeLaunch {
   uint32_t *work_count;
   float *bands;      // optional tap (may be null)
   uint8_t *units;    // frames*channels*212   (may be null for stage taps)
+  // speculative binary32 path
+  float *eps;            // frames*channels*kEpsFloats: per-band bound on |binary32 coefficient - reference coefficient|
+  uint32_t *redo_list;   // units whose decisions are not certain within the bound (filled by the pack kernel)
+  uint32_t *redo_count;
+  // list mode: when unit_list is non-null the kernels process units unit_list[0 .. *unit_count) instead of all
+  const uint32_t *unit_list;
+  const uint32_t *unit_count;
 };
 
 struct C1DecodeLaunch {
@@ -83,6 +106,7 @@ struct C1DecodeLaunch {
 // launchers (one per c1_k_*.hip file); all asynchronous on `stream`
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0]
+void c1k_launch_analysis_spec(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0], binary32 + error bound
 // transient detection: features (runs) -> decisions (per unit) -> MDCT from the stored bands (per unit).
 // bands_ws: (units + channels) * 512 floats, feat_ws: (units + channels) * kFeatureWsDoubles doubles, modes_ws: units bytes
 constexpr int kFeatureWsDoubles = 20;
@@ -91,6 +115,8 @@ void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws
                        hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
+void c1k_launch_pack_spec(const C1EncodeLaunch &L, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
+void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream);
 void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream);

@@ -190,9 +190,13 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
   const C1DevEncOpts *O = L.opts;
   const __attribute__((address_space(4))) double *biased = (const __attribute__((address_space(4))) double *)O->biased;
   const int lane = threadIdx.x;
-  const int64_t units_total = L.frames * L.channels;
-  const int64_t unit = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = unit < units_total;
+  // list mode (exact redo after the speculative pass): positions index L.unit_list
+  const bool listed = L.unit_list != nullptr;
+  const int64_t units_total = listed ? (int64_t)*L.unit_count : L.frames * L.channels;
+  for (int64_t pos0 = (int64_t)blockIdx.x * 64; pos0 < units_total; pos0 += (int64_t)gridDim.x * 64) {
+  const int64_t pos = pos0 + lane;
+  const bool live = pos < units_total;
+  const int64_t unit = listed ? (int64_t)L.unit_list[live ? pos : 0] : pos;
   uint32_t sf[13];
   load_sfi(L.side, live ? unit : 0, sf);
   uint64_t r0, r1, r2, r3;
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
     for (int c = 0; c < 7; c++)
       if ((survivors >> c) & 1u) L.work_list[at++] = ((uint32_t)(unit - (int64_t)0) << 3) | (uint32_t)c;
   }
+  }
 }
 
 __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L) {
@@ -264,8 +269,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L) {
 }
 
 __global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
-  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (unit >= L.frames * L.channels) return;
+  const bool listed = L.unit_list != nullptr;
+  const int64_t units_total = listed ? (int64_t)*L.unit_count : L.frames * L.channels;
+  for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < units_total; pos += (int64_t)gridDim.x * 256) {
+  const int64_t unit = listed ? (int64_t)L.unit_list[pos] : pos;
   const uint8_t *base = L.cand + unit * kCandBytes;
   const double *tot = reinterpret_cast<const double *>(base);
   double best = __builtin_huge_val();
@@ -284,15 +291,19 @@ __global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
     dst[0] = 0; dst[1] = 0; dst[2] = 0;
     dst[3] = 1ull << 59;                   // fallback (:132-139): 20 BFUs, all indices zero
   }
+  }
 }
 
 }  // namespace
 
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
+  const bool listed = L.unit_list != nullptr;            // the list's length is only known on the device: bounded grids stride over it
   (void)hipMemsetAsync(L.work_count, 0, sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(k_alloc_first, dim3((unsigned)((units + 63) / 64)), dim3(C1_WAVE), 0, stream, L);
+  const int64_t first_blocks = listed ? std::min<int64_t>((units + 63) / 64, 256 * 12) : (units + 63) / 64;
+  hipLaunchKernelGGL(k_alloc_first, dim3((unsigned)first_blocks), dim3(C1_WAVE), 0, stream, L);
   const int64_t rest_blocks = std::min<int64_t>((units * 7 + 63) / 64, 256 * 10);
   hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest_blocks), dim3(C1_WAVE), 0, stream, L);
-  hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, L);
+  const int64_t select_blocks = listed ? std::min<int64_t>((units + 255) / 256, 2048) : (units + 255) / 256;
+  hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)select_blocks), dim3(256), 0, stream, L);
 }

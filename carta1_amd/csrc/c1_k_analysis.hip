@@ -64,9 +64,17 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   const C1DevEncOpts *O = L.opts;
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
+  // list mode (exact redo of the units the speculative pass could not certify): one item = one unit, rebuilt from
+  // its own warm-up frame; otherwise one item = this workgroup's run of kRunFramesLong frames
+  const bool listed = L.unit_list != nullptr;
+  const int64_t n_items = listed ? (int64_t)*L.unit_count : (int64_t)gridDim.x;
+  for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const int64_t listed_unit = listed ? (int64_t)L.unit_list[item] : 0;
+  const int ch = listed ? (int)(listed_unit % L.channels) : (int)(blockIdx.x % L.channels);
+  const int64_t f0 = listed ? listed_unit / L.channels : (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
+  const int64_t run_frames = listed ? 1 : kRunFramesLong;
   const float *__restrict__ pcm = L.pcm[ch];
+  lane = lane0;
 
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
-  const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
+  const int64_t f_end = (f0 + run_frames < L.frames) ? f0 + run_frames : L.frames;
   constexpr int kWarm = 1;                         // one frame of history rebuilds the state
   int64_t f_first = f0 - kWarm;
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;   // before the stream start the zero state stays
@@ -244,6 +252,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       __syncthreads();
     }
   }
+  __syncthreads();
+  }
 }
 
 }  // namespace
@@ -256,6 +266,8 @@ void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t strea
 }
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
-  hipLaunchKernelGGL((k_analysis_fast<true>), dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+  // list mode: the number of listed units is only known on the device; a bounded grid strides over the list
+  const int64_t blocks = L.unit_list ? std::min<int64_t>(L.frames * L.channels, 256 * 16) : runs * L.channels;
+  hipLaunchKernelGGL((k_analysis_fast<true>), dim3((unsigned)blocks), dim3(C1_WAVE), 0, stream, L);
 }
 static_assert(sizeof(LongLds) <= 8192, "all-long analysis: 20 waves per CU need <= 8 KiB of LDS per wave");

@@ -47,6 +47,8 @@ struct PackLds {
   uint32_t words[56];         // the unit as big-endian 32-bit groups
   uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
   double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
+  float normf[52];            // speculative path: fl32 of the same, and the guard band eps_band * norm of the BFU
+  float guard[52];
 };
 
 // One wave per sound unit.  A lane owns 8 consecutive coefficient slots (BFU-major order == bitstream
@@ -61,7 +63,9 @@ struct PackHeader {   // what a lane needs of one unit's allocation and side rec
   uint32_t sd_sf;     // side dword holding this lane's scale-factor index              (side[lane >> 2])
   uint32_t sd_q;      // side dword lane & 15 (four scale factors for the 24-bit field, modes in dword 13)
   uint32_t al_a, al_b;   // allocation dwords (lane - 1) & 7 and lane & 7 (word-length bytes, lanes 0..7)
+  float eps;             // speculative path: eps[lane & 3] of the unit (bands 0..2, flag word)
 };
+template <bool SPEC>
 __device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, int64_t unit, int lane) {
   const uint32_t *al = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes);
   const uint32_t *side = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes);
@@ -72,19 +76,27 @@ __device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, 
   h.sd_q = side[lane & 15];
   h.al_a = al[(lane + 7) & 7];
   h.al_b = al[lane & 7];
+  h.eps = SPEC ? L.eps[unit * kEpsFloats + (lane & 3)] : 0.0f;
   return h;
 }
 
 // ALL_LONG: the caller knows every unit of the batch has modes [0,0,0] (fixed block modes): coefficient order ==
 // slot order, no per-slot position tables
-template <bool ALL_LONG>
+// SPEC: the coefficients come from the speculative binary32 analysis and carry a per-band bound eps on their distance
+// from the reference's (c1_k_spec.hip).  Then x * norm + 0.5 is formed in binary32 and a mantissa is accepted only
+// when no value within the bound (plus the rounding of this very computation) truncates to another integer; a unit
+// with any doubtful mantissa, or whose scale-factor indices were doubtful, goes to the redo list and is encoded
+// again by the exact kernels.
+template <bool ALL_LONG, bool SPEC>
 __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack(C1EncodeLaunch L) {
   __shared__ PackLds lds[kPackWaves];
-  __shared__ double norm_s[64 * 16];        // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
+  __shared__ typename std::conditional<SPEC, float, double>::type norm_s[64 * 16];   // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
   TablesPtr T = C1_TABLES(L.tables);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   PackLds &S = lds[wave];
-  for (int i = threadIdx.x; i < 64 * 16; i += C1_WAVE * kPackWaves) norm_s[i] = T->norm[i];
+  for (int i = threadIdx.x; i < 64 * 16; i += C1_WAVE * kPackWaves) {
+    if constexpr (SPEC) norm_s[i] = T->norm32[i]; else norm_s[i] = T->norm[i];
+  }
   __syncthreads();
   // which BFU / which coefficient each of this lane's 8 slots is, and where it sits for long / short blocks
   int slot_b[8], slot_j[8], at_long[8], at_short[8];
@@ -98,9 +110,12 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
   }
   const int my_size = lane < 52 ? kSpecs[lane] : 0;
   const int my_long = lane < 52 ? kStartLong[lane] : 0, my_short = lane < 52 ? kStartShort[lane] : 0;
-  const int64_t units_total = L.frames * L.channels;
+  // list mode (exact redo of the units the speculative pass could not certify): positions index L.unit_list
+  const bool listed = L.unit_list != nullptr;
+  const int64_t units_total = listed ? (int64_t)*L.unit_count : L.frames * L.channels;
   const int64_t stride = (int64_t)gridDim.x * kPackWaves;
   const int64_t u_first = (int64_t)blockIdx.x * kPackWaves + wave;
+  auto unit_at = [&](int64_t pos) -> int64_t { return listed ? (int64_t)L.unit_list[pos] : pos; };
   auto load_coefs = [&](int64_t unit, uint32_t modes_dword, float (&x)[8]) {
     const float *coefs = L.coefs + (unit << 9);
     const int modes = (int)(modes_dword & 0xff);
@@ -117,16 +132,17 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     }
   };
   if (u_first >= units_total) return;
-  PackHeader h0 = pack_load_header(L, u_first, lane);
-  PackHeader h1 = pack_load_header(L, u_first + stride < units_total ? u_first + stride : u_first, lane);
+  PackHeader h0 = pack_load_header<SPEC>(L, unit_at(u_first), lane);
+  PackHeader h1 = pack_load_header<SPEC>(L, unit_at(u_first + stride < units_total ? u_first + stride : u_first), lane);
   float x[8];
-  load_coefs(u_first, __shfl(h0.sd_q, 13), x);
-  for (int64_t unit = u_first; unit < units_total; unit += stride) {
+  load_coefs(unit_at(u_first), __shfl(h0.sd_q, 13), x);
+  for (int64_t pos = u_first; pos < units_total; pos += stride) {
+    const int64_t unit = unit_at(pos);
     // ---- issue the loads of the units ahead ----
-    const int64_t u1 = unit + stride, u2 = unit + 2 * stride;
-    PackHeader h2 = pack_load_header(L, u2 < units_total ? u2 : unit, lane);
+    const int64_t u1 = pos + stride, u2 = pos + 2 * stride;
+    PackHeader h2 = pack_load_header<SPEC>(L, unit_at(u2 < units_total ? u2 : pos), lane);
     float xn[8];
-    load_coefs(u1 < units_total ? u1 : unit, __shfl(h1.sd_q, 13), xn);
+    load_coefs(unit_at(u1 < units_total ? u1 : pos), __shfl(h1.sd_q, 13), xn);
     // ---- this unit ----
     const uint32_t a7 = h0.al7;
     const bool fallback = (a7 >> 27) & 1;
@@ -144,10 +160,18 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     const int bits_b = wl_bits(wl);
     const int mybits = bits_b * my_size;
     const int scan = wave_inclusive_scan(mybits);
+    const float eb = SPEC ? __shfl(h0.eps, lane >= 36 ? 2 : (lane >= 20 ? 1 : 0)) : 0.0f;
     if (lane < 52) {
       const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
       S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
-      S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
+      if constexpr (SPEC) {
+        const float nf = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0f;
+        const float g = eb * nf;
+        S.normf[lane] = nf;
+        S.guard[lane] = __builtin_fmaf(g, 9.5367431640625e-07f, g);       // * (1 + 2^-20)
+      } else {
+        S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
+      }
     }
     wave_sync();
     // header (serialization.js:46-53) and word-length indices (:55-64): the 4-bit indices are already
@@ -169,6 +193,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     uint64_t acc = 0;
     int cnt = -1, wi = 0;
     bool first = true;
+    bool doubtful = false;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const uint32_t dsc = S.desc[slot_b[m]];
@@ -178,12 +203,24 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
         cnt = pos & 31;                                         // phantom zero bits in front: a neighbour's bits
         wi = pos >> 5;
       }
-      const double xs = (double)x[m] * S.normd[slot_b[m]];
-      const double v = xs + (xs >= 0 ? 0.5 : -0.5);            // round half away from zero ...
-      int32_t y = (int32_t)v;                                  // ... then `| 0`: truncation; exact wrap below
-      if (__builtin_expect(!(fabs(v) < 2147483648.0), 0)) y = to_int32(v);
       const int32_t range = (1 << (bits > 0 ? bits - 1 : 0)) - 1;
-      y = y > range ? range : (y < -range ? -range : y);
+      int32_t y;
+      if constexpr (SPEC) {
+        // |x| * norm + 0.5 in one fused operation; the reference's value of it lies within et of a
+        const float a = __builtin_fmaf(fabsf(x[m]), S.normf[slot_b[m]], 0.5f);
+        const int32_t q = (int32_t)a;                           // truncation; a >= 0
+        const float d = a - (float)q;                           // exact
+        const float et = __builtin_fmaf(a, 2.384185791015625e-07f, S.guard[slot_b[m]]) + 2.384185791015625e-07f;   // + 2^-22 a + 2^-22
+        doubtful |= bits != 0 && !(d > et && d < 1.0f - et);
+        const int32_t qc = q > range ? range : q;
+        y = x[m] < 0.0f ? -qc : qc;
+      } else {
+        const double xs = (double)x[m] * S.normd[slot_b[m]];
+        const double v = xs + (xs >= 0 ? 0.5 : -0.5);            // round half away from zero ...
+        y = (int32_t)v;                                          // ... then `| 0`: truncation; exact wrap below
+        if (__builtin_expect(!(fabs(v) < 2147483648.0), 0)) y = to_int32(v);
+        y = y > range ? range : (y < -range ? -range : y);
+      }
       acc = (acc << bits) | ((uint32_t)y & ((1u << bits) - 1u));
       cnt += bits != 0 ? bits : 0;
       if (cnt >= 32) {                                          // a 32-bit group is complete
@@ -198,6 +235,11 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     if (cnt > 0) atomicOr(&S.words[wi], (uint32_t)(acc << (32 - cnt)));
     wave_sync();
     if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
+    if constexpr (SPEC) {
+      // flag word of the analysis (a scale-factor index was not certain) or any doubtful mantissa -> exact redo
+      const bool redo = __builtin_amdgcn_ballot_w64(doubtful) != 0 || __float_as_int(__shfl(h0.eps, 3)) != 0;
+      if (redo && lane == 0) L.redo_list[atomicAdd(L.redo_count, 1u)] = (uint32_t)unit;
+    }
     wave_sync();
     h0 = h1; h1 = h2;
 #pragma unroll
@@ -209,6 +251,10 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
 
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream) {
   const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
-  if (all_long) hipLaunchKernelGGL((k_pack<true>), grid, block, 0, stream, L);
-  else hipLaunchKernelGGL((k_pack<false>), grid, block, 0, stream, L);
+  if (all_long) hipLaunchKernelGGL((k_pack<true, false>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_pack<false, false>), grid, block, 0, stream, L);
+}
+void c1k_launch_pack_spec(const C1EncodeLaunch &L, hipStream_t stream) {
+  const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
+  hipLaunchKernelGGL((k_pack<true, true>), grid, block, 0, stream, L);
 }

@@ -39,7 +39,7 @@ extern "C" {
 #define C1_FRAME_SAMPLES 512
 #define C1_UNIT_BYTES 212
 #define C1_MAX_CHANNELS 2
-#define C1_ABI_VERSION 1
+#define C1_ABI_VERSION 2
 
 enum {
   C1_OK = 0,
@@ -101,10 +101,23 @@ int c1_ctx_create(int device, void *hip_stream /* hipStream_t or NULL = own stre
 int c1_ctx_destroy(c1_ctx *ctx);
 int c1_ctx_synchronize(c1_ctx *ctx);
 /* milliseconds the device spent in the named kernel during the most recent *_device call on this
- * context ("analysis", "allocate", "pack", "decode", or "total"), from HIP events on the context's
+ * context ("analysis", "allocate", "pack", "decode", "redo", or "total"), from HIP events on the context's
  * stream; c1_ctx_set_profiling(ctx, 1) must have been set before the call */
 int c1_ctx_set_profiling(c1_ctx *ctx, int enabled);
 int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches);
+
+/* Speculative encoding of fixed-block-mode streams.  The encoder's outputs are integers; they are
+ * decisions taken on the MDCT coefficients (bitallocation.js:290-299, quantization.js:43-53).  For fixedBlockModes
+ * [0,0,0] the library first computes the coefficients in binary32 together with a proven bound on their distance
+ * from the reference's binary64-then-rounded values, accepts every sound unit whose decisions are the same for all
+ * values within the bound, and re-encodes the others with the exact kernels: the result is bit-identical to the
+ * exact path by construction.  mode: 0 = exact kernels only, 1 = adaptive (default; a stream that had to redo more
+ * than 30 % of its units is sent to the exact kernels, re-probed every 16th call), 2 = always speculate.
+ * The environment variable C1_SPEC (0/1/2) sets the default of new contexts. */
+int c1_ctx_set_speculation(c1_ctx *ctx, int mode);
+/* units encoded through the speculative pass and units among them that were redone exactly, since the context was
+ * created (or since the last call with reset != 0); synchronises the context's stream */
+int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset);
 
 /* ---- encode: replaces the encode() frame closure body, encoder.js:438-450
  *      (qmfAnalysisStage :57-96, blockSelectorStage :111-152, mdctStage :170-349,
@@ -185,6 +198,13 @@ int c1_aea_header(const char *title, uint32_t unit_count, int channels, uint8_t 
 int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
                             int halo_frames, const c1_encode_options *opts, float *bands,
                             float *coefs, uint8_t *side, uint8_t *alloc /* frames*channels*32 or NULL */);
+
+/* The speculative binary32 analysis on its own (diagnostics; tests/test_gpu_spec.py checks the bound with it):
+ * coefs: frames*channels*512 floats = the binary32 coefficients; eps: frames*channels*4 floats = the proven bound on
+ * |coefficient - reference coefficient| for bands 0, 1, 2 and a flag word (non-zero bit pattern: a scale-factor
+ * index was not certain); side as above.  Fixed block modes [0,0,0] only (C1_ERR_ARG otherwise). */
+int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                          const c1_encode_options *opts, float *coefs, float *eps, uint8_t *side);
 
 #ifdef __cplusplus
 }
