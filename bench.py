@@ -86,6 +86,7 @@ def main():
     ap.add_argument('--decode', action='store_true', help='time decode of the encoded units instead')
     ap.add_argument('--cpu-sample', type=int, default=65536, help='stereo frames for the CPU baseline (0 = skip)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo for rehearsals')
+    ap.add_argument('--no-extras', action='store_true', help='headline workload only (profiling runs)')
     ap.add_argument('--force-device', type=int, default=-1, help='rehearsal only: put every rank on this device')
     args = ap.parse_args()
 
@@ -164,7 +165,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     # per-kernel device time of the LAST step (events recorded on the library's stream inside the timed region)
-    for name in (('decode',) if args.decode else ('analysis', 'allocate', 'pack')):
+    for name in (('decode',) if args.decode else ('analysis', 'allocate', 'pack', 'redo')):
         ms, n = ctx.kernel_ms(name)
         kernel_ms[name] = {'ms_per_step': ms, 'launches_per_step': n}
     ctx.set_profiling(False)

@@ -92,6 +92,9 @@ float round_up_f32(double x) {
 }
 void build_spec_tables(const c1_tables &t, C1DevTables *d) {
   for (int j = 0; j < 24; j++) d->tap32[j] = (float)d->tap_e[j];
+  for (int j = 0; j < 24; j++) { d->tap_pair[j][0] = d->tap32[23 - j]; d->tap_pair[j][1] = d->tap32[j]; }
+  d->tap_pair[24][0] = 0.0f; d->tap_pair[24][1] = d->tap32[11];
+  d->tap_pair[25][0] = d->tap32[11]; d->tap_pair[25][1] = 0.0f;
   bool ok = d->sf_fast != 0;
   for (int i = 0; i < 32; i++) {
     d->win32[i] = (float)t.window_short[i];

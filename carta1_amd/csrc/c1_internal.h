@@ -33,6 +33,7 @@ struct C1DevTables {
   double inv_range[16];      // RN(1 / (2^(wl) - 1)) by word-length index wl = 1..15
   // ---- binary32 tables of the speculative path (c1_k_spec.hip): roundings of the tables above ----
   float tap32[24];           // QMF_EVEN (binary32 in the reference already)
+  float tap_pair[26][2];     // (E[23-j], E[j]) for j < 24: one packed FMA advances an (odd, even) chain pair; then (0, E[11]), (E[11], 0)
   float win32[32];           // fl32(WINDOW_SHORT)
   float pre32_64[16][2];     // fl32 of the MDCT (cos, sin) pairs
   float pre32_256[64][2];
@@ -92,6 +93,7 @@ struct C1EncodeLaunch {
   // list mode: when unit_list is non-null the kernels process units unit_list[0 .. *unit_count) instead of all
   const uint32_t *unit_list;
   const uint32_t *unit_count;
+  int run_frames;        // consecutive frames of one channel a wave walks (set by the launchers, c1k_pick_run)
 };
 
 struct C1DecodeLaunch {
@@ -101,7 +103,29 @@ struct C1DecodeLaunch {
   int halo_units;
   const C1DevTables *tables;
   float *pcm[C1_MAX_CHANNELS];
+  int run_frames;        // consecutive units of one channel a wave decodes (set by the launcher)
 };
+
+// Run length of the frame-walking kernels.  Every wave of a launch does the same amount of work, so a grid of W waves
+// on a machine with S wave slots takes ceil(W / S) rounds: 16 384 runs of 64 frames on 5 120 slots are 4 rounds, the
+// last one a fifth full.  The launchers therefore size the runs so that one launch fills the slots once (long runs
+// also amortise the warm-up frame), and never below kMinRun frames, where the warm-up would cost too much.
+constexpr int kMinRun = 16;
+inline int c1k_pick_run(int64_t frames, int channels, int slots) {
+  const int64_t runs_per_channel = slots / channels > 0 ? slots / channels : 1;
+  int64_t run = (frames + runs_per_channel - 1) / runs_per_channel;
+  if (run < kMinRun) run = kMinRun;
+  if (run > (1 << 20)) run = 1 << 20;
+  return (int)run;
+}
+// wave slots of the current device for a 64-thread kernel (occupancy x compute units), cached by the caller
+template <class Kernel>
+inline int c1k_wave_slots(Kernel kernel) {
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  return per_cu * cus;
+}
 
 // launchers (one per c1_k_*.hip file); all asynchronous on `stream`
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);

@@ -65,14 +65,14 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   const int lane0 = threadIdx.x;
   int lane = lane0;
   // list mode (exact redo of the units the speculative pass could not certify): one item = one unit, rebuilt from
-  // its own warm-up frame; otherwise one item = this workgroup's run of kRunFramesLong frames
+  // its own warm-up frame; otherwise one item = this workgroup's run of L.run_frames frames
   const bool listed = L.unit_list != nullptr;
   const int64_t n_items = listed ? (int64_t)*L.unit_count : (int64_t)gridDim.x;
   for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
   const int64_t listed_unit = listed ? (int64_t)L.unit_list[item] : 0;
   const int ch = listed ? (int)(listed_unit % L.channels) : (int)(blockIdx.x % L.channels);
-  const int64_t f0 = listed ? listed_unit / L.channels : (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
-  const int64_t run_frames = listed ? 1 : kRunFramesLong;
+  const int64_t f0 = listed ? listed_unit / L.channels : (int64_t)(blockIdx.x / L.channels) * L.run_frames;
+  const int64_t run_frames = listed ? 1 : L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
   lane = lane0;
 
@@ -258,14 +258,20 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
 
 }  // namespace
 
-void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
+void c1k_launch_analysis(const C1EncodeLaunch &L0, bool detect, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_analysis_fast<false>);
+  C1EncodeLaunch L = L0;
+  L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
   const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
   (void)detect;
   hipLaunchKernelGGL((k_analysis_fast<false>), grid, block, 0, stream, L);
 }
-void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
+void c1k_launch_analysis_long(const C1EncodeLaunch &L0, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_analysis_fast<true>);
+  C1EncodeLaunch L = L0;
+  L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
   // list mode: the number of listed units is only known on the device; a bounded grid strides over the list
   const int64_t blocks = L.unit_list ? std::min<int64_t>(L.frames * L.channels, 256 * 16) : runs * L.channels;
   hipLaunchKernelGGL((k_analysis_fast<true>), dim3((unsigned)blocks), dim3(C1_WAVE), 0, stream, L);

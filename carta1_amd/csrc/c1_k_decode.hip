@@ -154,7 +154,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesDecode;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * L.run_frames;
   float *__restrict__ pcm = L.pcm[ch];
 
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
-  const int64_t f_end = (f0 + kRunFramesDecode < L.frames) ? f0 + kRunFramesDecode : L.frames;
+  const int64_t f_end = (f0 + L.run_frames < L.frames) ? f0 + L.run_frames : L.frames;
   for (int64_t f = f0 - 1; f < f_end; ++f) {
     if (f < -(int64_t)L.halo_units) continue;
     const bool emit = f >= f0;
@@ -353,7 +353,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
 
 }  // namespace
 
-void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFramesDecode - 1) / kRunFramesDecode;
+void c1k_launch_decode(const C1DecodeLaunch &L0, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_decode);
+  C1DecodeLaunch L = L0;
+  L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
   hipLaunchKernelGGL(k_decode, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
 }

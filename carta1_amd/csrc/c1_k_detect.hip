@@ -81,7 +81,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
-  const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
+  const int64_t f_end = (f0 + L.run_frames < L.frames) ? f0 + L.run_frames : L.frames;
   int64_t f_first = f0 - 2;                                  // frame -2 rebuilds the QMF delay lines, frame -1 the magnitudes
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;
   if (f_first > f0) f_first = f0;
@@ -504,9 +504,12 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
 
 }  // namespace
 
-void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
+void c1k_launch_detect(const C1EncodeLaunch &L0, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
                        hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong, units = L.frames * L.channels;
+  static const int slots = c1k_wave_slots(k_detect_features);
+  C1EncodeLaunch L = L0;
+  L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames, units = L.frames * L.channels;
   (void)hipMemsetAsync(lists_ws, 0, 4 * sizeof(uint32_t), stream);
   hipLaunchKernelGGL(k_detect_features, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
   hipLaunchKernelGGL(k_detect_decide, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, feat_ws, L.channels, L.frames,

@@ -23,17 +23,19 @@ namespace {
 // mem is reused inside a frame (one wave: LDS operations execute in issue order, so a region may be rewritten as
 // soon as every read of its previous content has been issued):
 //   R1 = mem[0, 840)      stage-1 work buffer (blocks of 8 samples padded to 12 floats: conflict-free 16-byte
-//                         window reads at "lane base + immediate")  ->  in2 (512)  ->  FFT points z (320 float2)
+//                         window reads at "lane base + immediate")  ->  in2 (512, from mem[1]: a lane's four high-band
+//                         outputs then start a 16-byte group)  ->  FFT points z (320 float2)
+// The zero padding of the long-block MDCT inputs is never materialised: the pre-twiddle knows which of its operands
+// fall into it (a lane-constant predicate) and takes 0 instead of reading.
 //   R2 = mem[840, 1352)   stage-2 work buffer (302)  ->  in0 | in1 (256 each)  ->  coefficients (512)
 constexpr int kR2 = 840;
 constexpr int kMemFloats = kR2 + 512;
+constexpr int kIn2 = 1;             // in2[i] = mem[kIn2 + i]
 struct alignas(16) SpecLds {
   alignas(16) float mem[kMemFloats];
   alignas(16) float d1[48];          // stage-1 delay line (46)
   alignas(16) float d2[48];          // stage-2 delay line (46)
-  alignas(16) float pre0[32];        // what the next frame's MDCT inputs start with: windowed overlap of bands 0, 1 ...
-  alignas(16) float pre1[32];
-  alignas(16) float pre2[72];        // ... and of band 2 (32), then the 39 delayed high-band samples
+  alignas(16) float pre2[72];        // what the next frame's band-2 MDCT input starts with: windowed overlap (32), then the 39 delayed samples
   alignas(16) float win[32];         // fl32(WINDOW_SHORT)
   alignas(4) uint8_t sfi[64];
 };
@@ -59,110 +61,124 @@ __device__ __forceinline__ float wave_sum(float x) {
   return (lane_value(x, 0) + lane_value(x, 16)) + (lane_value(x, 32) + lane_value(x, 48));
 }
 
-// D consecutive outputs of the decimating QMF from the lane's window w[0 .. 46 + 2 D): output d uses w[2 d ..]:
-//   even = sum_j E[j] w[2 d + 47 - 2 j],  odd = sum_m E[m] w[2 d + 2 m]   (QMF_ODD[j] = QMF_EVEN[23 - j])
-// each as chain A (taps 0..11 ascending) + chain B (taps 23..13 descending), then the centre tap 12.
-template <int D, int N>
-__device__ __forceinline__ void qmf_core_f32(const float (&w)[N], TablesPtr T, float (&lo)[D], float (&hi)[D]) {
-  float tap[24];
+// ---- packed binary32 arithmetic -------------------------------------------------------------------------------------
+// On CDNA a wave64 vector instruction occupies its SIMD for four cycles whatever its type; the binary32 peak needs the
+// packed forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations per lane and instruction
+// on an aligned register pair).  The kernel is written on 2-vectors so that every pair it operates on is one the data
+// already forms: the (even, odd) sample pairs of a 16-byte LDS read, (re, im) of a complex point.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f V2(float x, float y) { v2f r; r.x = x; r.y = y; return r; }
+
+// D consecutive outputs of the decimating QMF from the lane's window w[0 .. 46 + 2 D), held as the pairs
+// W[k] = (w[2 k], w[2 k + 1]).  Output d uses w[2 d ..]:
+//   even = sum_j E[j] w[2 d + 47 - 2 j],   odd = sum_m E[m] w[2 d + 2 m]        (QMF_ODD[j] = QMF_EVEN[23 - j])
+// Each sum is chain A (taps 0..11 ascending) + chain B (taps 23..13 descending), then the centre tap 12: the small
+// outer taps first, the largest last (that order keeps the rounding bound small).  Term j of the even
+// sum and term 23 - j of the odd sum read the two halves of the same pair W[d + 23 - j], so one packed FMA with the
+// tap pair (E[23 - j], E[j]) advances (odd chain, even chain) together:
+//   P1 = (odd B-chain m = 23..13 , even A-chain j = 0..10)      P2 = (odd A-chain m = 0..10 , even B-chain j = 23..13)
+// then the two terms with tap 11 (a packed FMA whose other half multiplies by 0: x + 0 * w is exact), P1 + P2, and
+// the centre taps as two plain FMAs.
+template <int D, int NP>
+__device__ __forceinline__ void qmf_core_f32(const v2f (&W)[NP], TablesPtr T, float (&lo)[D], float (&hi)[D]) {
+  v2f tp[26];                                            // wave-uniform: aligned SGPR pairs, straight into the packed FMAs
 #pragma unroll
-  for (int j = 0; j < 24; j++) tap[j] = T->tap32[j];
+  for (int j = 0; j < 26; j++) tp[j] = *reinterpret_cast<const __attribute__((address_space(4))) v2f *>(T->tap_pair[j]);
+  const float e12 = T->tap32[12];
 #pragma unroll
   for (int d = 0; d < D; d++) {
-    const int o = 2 * d;
-    float a = tap[0] * w[o + 47];
+    v2f p1 = W[d + 23] * tp[0];
 #pragma unroll
-    for (int j = 1; j <= 11; j++) a = __builtin_fmaf(tap[j], w[o + 47 - 2 * j], a);
-    float b = tap[23] * w[o + 1];
+    for (int j = 1; j <= 10; j++) p1 = pk_fma(W[d + 23 - j], tp[j], p1);
+    v2f p2 = W[d] * tp[23];
 #pragma unroll
-    for (int j = 22; j >= 13; j--) b = __builtin_fmaf(tap[j], w[o + 47 - 2 * j], b);
-    const float ev = __builtin_fmaf(tap[12], w[o + 23], a + b);
-    float c = tap[0] * w[o];
-#pragma unroll
-    for (int m = 1; m <= 11; m++) c = __builtin_fmaf(tap[m], w[o + 2 * m], c);
-    float e = tap[23] * w[o + 46];
-#pragma unroll
-    for (int m = 22; m >= 13; m--) e = __builtin_fmaf(tap[m], w[o + 2 * m], e);
-    const float od = __builtin_fmaf(tap[12], w[o + 24], c + e);
+    for (int j = 22; j >= 13; j--) p2 = pk_fma(W[d + 23 - j], tp[j], p2);
+    p1 = pk_fma(W[d + 12], tp[24], p1);           // even j = 11: w[2 d + 25]
+    p2 = pk_fma(W[d + 11], tp[25], p2);           // odd  m = 11: w[2 d + 22]
+    const v2f sum = p1 + p2;                             // (odd B + odd A, even A + even B)
+    const float ev = __builtin_fmaf(e12, W[d + 11].y, sum.y);   // w[2 d + 23]
+    const float od = __builtin_fmaf(e12, W[d + 12].x, sum.x);   // w[2 d + 24]
     lo[d] = ev + od;
     hi[d] = ev - od;
   }
 }
 
-__device__ __forceinline__ float2 cmul32(float2 x, float2 w) {
-  return make_float2(__builtin_fmaf(x.x, w.x, -(x.y * w.y)), __builtin_fmaf(x.x, w.y, x.y * w.x));
+// Multiplying by +-1 is exact, so "negate one half" and "swap and negate" ride on an FMA or a product with one of
+// these constant pairs instead of costing sign-bit instructions of their own.
+#define PMN V2(1.0f, -1.0f)
+#define PNM V2(-1.0f, 1.0f)
+// complex product (x.x + i x.y)(w.x + i w.y): two products rounded, then two fused
+__device__ __forceinline__ v2f cmul32(v2f x, v2f w) {
+  const v2f wr = w.yx * PNM;                             // (-w.y, w.x), exact
+  const v2f t = x.yy * wr;                               // (-(x.y w.y), x.y w.x)
+  return pk_fma(x.xx, w, t);
 }
-__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-__device__ __forceinline__ float2 table_f2(TablesRsrc R, int byte_offset) {
+__device__ __forceinline__ v2f table_f2(TablesRsrc R, int byte_offset) {
   const auto v = __builtin_amdgcn_raw_buffer_load_b64(R, byte_offset, 0, 0);
-  float2 d;
+  v2f d;
   __builtin_memcpy(&d, &v, sizeof d);
   return d;
 }
 
 // lane-only geometry of the long-block core (same ownership as mdct_long_r4: lanes 0..15 band 0, 16..31 band 1,
-// 32..63 band 2, four FFT points per lane), with the MDCT inputs at mem[kR2] (in0), mem[kR2 + 256] (in1), mem[0] (in2)
-struct SpecGeometry {
-  int ia[4], ic[4], ib0, id0, ib3, id3;
-  int pre_tab[4];
+// 32..63 band 2, four FFT points per lane), with the MDCT inputs at mem[kR2] (in0), mem[kR2 + 256] (in1), mem[0] (in2).
+// Only a few base values stay in registers across the frame loop; the 40-odd addresses of a frame are one add or
+// multiply-add away from them (the register file, not the VALU, limits how many waves this kernel keeps in flight).
+struct SpecBase {
+  int ia0, ic0;      // float index of operands a, c of the lane's first point (position 4g)
+  int q2;            // 2 * (points per quarter): the four points of a lane are 2 q2 input samples apart
+  int ib, id;        // float index of the one (b, d) operand pair of the lane that is not zero padding (if any)
+  int pt0;           // byte offset of the pre-twiddle pair of the first point
   int za, zb, zc, zd;
-  int twb, twc, twd;
-  int cx[4], cy[4];
-  int post_tab[4];
-  bool band2;
+  int g;
+  int e0, e1;        // coefficient indices 2 i and n2 - 1 - 2 i of the lane's first final point (band offset included)
+  int po0;           // byte offset of its post-twiddle pair
+  bool band0, band2, use_lo, use_hi;
 };
-__device__ __forceinline__ SpecGeometry spec_geometry(int lane) {
-  SpecGeometry G;
+__device__ __forceinline__ SpecBase spec_base(int lane) {
+  SpecBase B;
   const int band = lane < 16 ? 0 : (lane < 32 ? 1 : 2);
   const int g = lane - (band == 0 ? 0 : (band == 1 ? 16 : 32));
   const int n4 = band == 2 ? 128 : 64, q = n4 / 4;
   const int r = bitrev(g, band == 2 ? 5 : 4);
-  const int in_base = band == 0 ? kR2 : (band == 1 ? kR2 + 256 : 0);
+  const int in_base = band == 0 ? kR2 : (band == 1 ? kR2 + 256 : kIn2);
   const int tab_base = band == 2 ? (int)offsetof(C1DevTables, pre32_512) : (int)offsetof(C1DevTables, pre32_256);
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int jp = ((j & 1) << 1) | (j >> 1);
-    const int k = r + q * jp, i = 2 * k;
-    G.ia[j] = in_base + 3 * n4 - 1 - i;
-    G.ic[j] = in_base + n4 + i;
-    G.pre_tab[j] = tab_base + 8 * k;
-  }
-  G.ib0 = in_base + 3 * n4 + 2 * r;
-  G.id0 = in_base + n4 - 1 - 2 * r;
-  const int i3 = 2 * (r + 3 * q);
-  G.ib3 = in_base + i3 - n4;
-  G.id3 = in_base + 5 * n4 - 1 - i3;
+  B.ia0 = in_base + 3 * n4 - 1 - 2 * r;
+  B.ic0 = in_base + n4 + 2 * r;
+  B.q2 = 2 * q;
+  // Long-block inputs are zero outside [ws, ws + 32 + band length).  Of a lane's four points only position 0 (first
+  // half of the pre-twiddle, mdct.js:76-89) and position 3 (second half, :91-105) have operands b, d at all inside
+  // the 2 N/4 outer samples, and they are non-zero for r < 8 (position 0) or r >= n4/4 - 8 (position 3) only.
+  B.use_lo = r < 8;
+  B.use_hi = r >= q - 8;
+  B.ib = B.use_lo ? in_base + 3 * n4 + 2 * r : in_base + 2 * r + 2 * q;
+  B.id = B.use_lo ? in_base + n4 - 1 - 2 * r : in_base + 14 * q - 1 - 2 * r;
+  B.pt0 = tab_base + 8 * r;
   const int pbase = band == 0 ? 0 : (band == 1 ? 64 : 128);
-  G.za = zslot(pbase + 4 * g);
-  G.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
-  G.twb = (int)offsetof(C1DevTables, r4b) + 24 * (g & 3);
-  G.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
-  G.twc = (int)offsetof(C1DevTables, r4c) + 24 * (g & 15);
-  G.band2 = band == 2;
-  G.zd = zslot(128 + (g & 31));
-  G.twd = (int)offsetof(C1DevTables, r2d) + 8 * (g & 31);
+  B.za = zslot(pbase + 4 * g);
+  B.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
+  B.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
+  B.zd = zslot(128 + (g & 31));
+  B.g = g;
   const int cbase = band == 0 ? 0 : (band == 1 ? 128 : 256), n2 = 2 * n4;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int i = band == 2 ? g + (j == 1 ? 64 : (j == 2 ? 32 : (j == 3 ? 96 : 0))) : g + 16 * j;
-    G.post_tab[j] = tab_base + 8 * i;
-    const int e0 = cbase + 2 * i, e1 = cbase + n2 - 1 - 2 * i;
-    G.cx[j] = band == 0 ? e0 : e1;
-    G.cy[j] = band == 0 ? e1 : e0;
-  }
-  return G;
+  B.e0 = cbase + 2 * g;
+  B.e1 = cbase + n2 - 1 - 2 * g;
+  B.po0 = tab_base + 8 * g;
+  B.band0 = band == 0;
+  B.band2 = band == 2;
+  return B;
 }
 
 // one radix-4 round over two reference stages: x1, x2, x3 times wa, wb, wa*wb, then the 4-point butterfly
-__device__ __forceinline__ void radix4_round(float2 (&x)[4], float2 wa, float2 wb, float2 wab) {
-  const float2 y1 = cmul32(x[1], wa), y2 = cmul32(x[2], wb), y3 = cmul32(x[3], wab);
-  const float2 t0 = x[0] + y1, t1 = x[0] - y1, t2 = y2 + y3, t3 = y2 - y3;
+__device__ __forceinline__ void radix4_round(v2f (&x)[4], v2f wa, v2f wb, v2f wab) {
+  const v2f y1 = cmul32(x[1], wa), y2 = cmul32(x[2], wb), y3 = cmul32(x[3], wab);
+  const v2f t0 = x[0] + y1, t1 = x[0] - y1, t2 = y2 + y3, t3 = y2 - y3;
   x[0] = t0 + t2;
   x[2] = t0 - t2;
-  x[1] = make_float2(t1.x + t3.y, t1.y - t3.x);
-  x[3] = make_float2(t1.x - t3.y, t1.y + t3.x);
+  x[1] = pk_fma(t3.yx, PMN, t1);                         // t1 - i t3 = t1 + (t3.y, -t3.x)
+  x[3] = pk_fma(t3.yx, PNM, t1);                         // t1 + i t3
 }
 
 __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) {
@@ -170,21 +186,22 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * kRunFramesLong;
+  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
   float *mem = S.mem;
 
   for (int i = lane; i < 48; i += 64) { S.d1[i] = 0.0f; S.d2[i] = 0.0f; }
-  if (lane < 32) { S.pre0[lane] = 0.0f; S.pre1[lane] = 0.0f; S.win[lane] = C1_TABLES(L.tables)->win32[lane]; }
+  if (lane < 32) S.win[lane] = C1_TABLES(L.tables)->win32[lane];
+  float ov0a = 0.0f, ov0b = 0.0f, ov1a = 0.0f, ov1b = 0.0f;   // lanes 48..63: windowed overlap of bands 0, 1 for the next frame
   for (int i = lane; i < 72; i += 64) S.pre2[i] = 0.0f;
   if (lane < 16) reinterpret_cast<uint32_t *>(S.sfi)[lane] = 0u;
-  const SpecGeometry G = spec_geometry(lane0);
-  const SfLong SFL = sf_long_geometry(lane0);
+  const SpecBase B0 = spec_base(lane0);
+  const SfLong SFL0 = sf_long_geometry(lane0);
   const TablesRsrc RT = tables_rsrc(L.tables);
   float p_prev = 0.0f, q_prev = 0.0f;        // PCM / stage-1-low energies of the previous frame
   __syncthreads();
 
-  const int64_t f_end = (f0 + kRunFramesLong < L.frames) ? f0 + kRunFramesLong : L.frames;
+  const int64_t f_end = (f0 + L.run_frames < L.frames) ? f0 + L.run_frames : L.frames;
   int64_t f_first = f0 - 1;                   // one frame of history rebuilds the state
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;
   if (f_first > f0) f_first = f0;
@@ -202,94 +219,105 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     float P;
     {
       const float4 a = pre_a, b = pre_b;
-      if (f + 1 < f_end) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
-        pre_a = p4[lane]; pre_b = p4[64 + lane];
+      // sample 4 lane + j of the frame sits at work index 46 + 4 lane + j: shifted by two samples against the lanes'
+      // 16-byte groups.  Each lane takes the last two samples of its left neighbour (DPP wave shift) and writes
+      // whole groups; the delay line is written afterwards and covers the two slots lane 0 filled with junk.
+      {
+        const float pz = dpp_read<0x138>(a.z), pw = dpp_read<0x138>(a.w);          // wave_shr:1
+        const float qz0 = dpp_read<0x138>(b.z), qw0 = dpp_read<0x138>(b.w);
+        const float az63 = lane_value(a.z, 63), aw63 = lane_value(a.w, 63);
+        const float qz = lane == 0 ? az63 : qz0, qw = lane == 0 ? aw63 : qw0;
+        const int v = 44 + 4 * lane;
+        *reinterpret_cast<float4 *>(&mem[w1_phys(v)]) = make_float4(pz, pw, a.x, a.y);
+        *reinterpret_cast<float4 *>(&mem[w1_phys(v + 256)]) = make_float4(qz, qw, b.x, b.y);
+        if (lane == 63) *reinterpret_cast<float2 *>(&mem[w1_phys(556)]) = make_float2(b.z, b.w);
+        if (lane < 46) mem[w1_phys(lane)] = S.d1[lane];
       }
-      if (lane < 46) mem[w1_phys(lane)] = S.d1[lane];
-      const int v = 46 + 4 * lane;
-      *reinterpret_cast<float2 *>(&mem[w1_phys(v)]) = make_float2(a.x, a.y);
-      *reinterpret_cast<float2 *>(&mem[w1_phys(v + 2)]) = make_float2(a.z, a.w);
-      *reinterpret_cast<float2 *>(&mem[w1_phys(v + 256)]) = make_float2(b.x, b.y);
-      *reinterpret_cast<float2 *>(&mem[w1_phys(v + 258)]) = make_float2(b.z, b.w);
-      float p = a.x * a.x;
-      p = __builtin_fmaf(a.y, a.y, p); p = __builtin_fmaf(a.z, a.z, p); p = __builtin_fmaf(a.w, a.w, p);
-      p = __builtin_fmaf(b.x, b.x, p); p = __builtin_fmaf(b.y, b.y, p); p = __builtin_fmaf(b.z, b.z, p); p = __builtin_fmaf(b.w, b.w, p);
+      v2f p2 = V2(a.x, a.y) * V2(a.x, a.y);
+      p2 = pk_fma(V2(a.z, a.w), V2(a.z, a.w), p2);
+      p2 = pk_fma(V2(b.x, b.y), V2(b.x, b.y), p2);
+      p2 = pk_fma(V2(b.z, b.w), V2(b.z, b.w), p2);
+      const float p = p2.x + p2.y;
       P = wave_sum(p);
     }
     __syncthreads();
     // ---------------- first QMF stage ----------------
     float Q;
     {
-      float w[56];
-      const float4 *src = reinterpret_cast<const float4 *>(mem + 12 * lane);
-#pragma unroll
-      for (int k = 0; k < 14; k++) {
-        const float4 t = src[3 * (k >> 1) + (k & 1)];      // floats 12 (k >> 1) + 4 (k & 1)
-        w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
-      }
       float lo[4], hi[4];
-      if (own_block()) qmf_core_f32<4>(w, T, lo, hi); else { for (int d = 0; d < 4; d++) { lo[d] = w[d]; hi[d] = 1.0f; } }
+      if (own_block()) {
+        v2f W[28];
+        const float4 *src = reinterpret_cast<const float4 *>(mem + 12 * lane);
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+          const float4 t = src[3 * (k >> 1) + (k & 1)];      // floats 12 (k >> 1) + 4 (k & 1): blocks of 8 padded to 12
+          W[2 * k] = V2(t.x, t.y); W[2 * k + 1] = V2(t.z, t.w);
+        }
+        qmf_core_f32<4>(W, T, lo, hi);
+      } else { for (int d = 0; d < 4; d++) { lo[d] = mem[lane + d]; hi[d] = 1.0f; } }
+      if (f + 1 < f_end) {      // the next frame's PCM: requested once the window registers are free, used a frame later
+        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
+        pre_a = p4[lane]; pre_b = p4[64 + lane];
+      }
       if (lane < 46) { S.d1[lane] = mem[w1_phys(512 + lane)]; mem[kR2 + lane] = S.d2[lane]; }
       *reinterpret_cast<float2 *>(&mem[kR2 + 46 + 4 * lane]) = make_float2(lo[0], lo[1]);
       *reinterpret_cast<float2 *>(&mem[kR2 + 48 + 4 * lane]) = make_float2(lo[2], lo[3]);
-      float q = lo[0] * lo[0];
-      q = __builtin_fmaf(lo[1], lo[1], q); q = __builtin_fmaf(lo[2], lo[2], q); q = __builtin_fmaf(lo[3], lo[3], q);
+      v2f q2 = V2(lo[0], lo[1]) * V2(lo[0], lo[1]);
+      q2 = pk_fma(V2(lo[2], lo[3]), V2(lo[2], lo[3]), q2);
+      const float q = q2.x + q2.y;
       Q = wave_sum(q);
       // band 2 = the high band behind its 39-sample delay (encoder.js:84-90): what the previous frame left (overlap,
       // 39 samples), then this frame's outputs; the last 32 samples of the band are windowed (encoder.js:309-316)
-      if (emit) {
-        for (int i = lane; i < 71; i += 64) mem[112 + i] = S.pre2[i];
-        const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (lane < 56) *reinterpret_cast<float4 *>(&mem[lane < 28 ? 4 * lane : 400 + 4 * (lane - 28)]) = zero4;   // [0,112), [400,512)
-      }
+      if (emit) for (int i = lane; i < 71; i += 64) mem[kIn2 + 112 + i] = S.pre2[i];
+      if (lane <= 45) {                                     // positions 39 + 4 lane .. + 3 < 224: plain samples, one 16-byte group
+        if (emit) *reinterpret_cast<float4 *>(&mem[kIn2 + 183 + 4 * lane]) = make_float4(hi[0], hi[1], hi[2], hi[3]);
+      } else {
 #pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const int pos = 39 + 4 * lane + d;                  // position in band 2 of this frame
-        const float x = hi[d];
-        if (pos < 224) { if (emit) mem[144 + pos] = x; }
-        else if (pos < 256) {
-          const int k = pos - 224;
-          S.pre2[k] = S.win[k] * x;
-          if (emit) mem[144 + pos] = x * S.win[31 - k];
-        } else S.pre2[32 + pos - 256] = x;
+        for (int d = 0; d < 4; d++) {
+          const int pos = 39 + 4 * lane + d;                // position in band 2 of this frame
+          const float x = hi[d];
+          if (pos < 224) { if (emit) mem[kIn2 + 144 + pos] = x; }
+          else if (pos < 256) {
+            const int k = pos - 224;
+            S.pre2[k] = S.win[k] * x;
+            if (emit) mem[kIn2 + 144 + pos] = x * S.win[31 - k];
+          } else S.pre2[32 + pos - 256] = x;
+        }
       }
     }
     __syncthreads();
     // ---------------- second QMF stage ----------------
     {
-      float w[52];
-      const float4 *src = reinterpret_cast<const float4 *>(mem + kR2 + 4 * lane);
-#pragma unroll
-      for (int k = 0; k < 13; k++) {
-        const float4 t = src[k];
-        w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
-      }
       float lo[2], hi[2];
-      if (own_block()) qmf_core_f32<2>(w, T, lo, hi); else { for (int d = 0; d < 2; d++) { lo[d] = w[d]; hi[d] = 1.0f; } }
-      if (lane < 46) S.d2[lane] = mem[kR2 + 256 + lane];
-      if (emit) {
-        if (lane < 32) { mem[kR2 + 48 + lane] = S.pre0[lane]; mem[kR2 + 256 + 48 + lane] = S.pre1[lane]; }
-        const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (lane < 48) {
-          const int b = lane < 24 ? 0 : 256, q = lane < 24 ? lane : lane - 24;      // 24 float4 per band: [0,48) and [208,256)
-          *reinterpret_cast<float4 *>(&mem[kR2 + b + (q < 12 ? 4 * q : 208 + 4 * (q - 12))]) = zero4;
+      if (own_block()) {
+        v2f W[26];
+        const float4 *src = reinterpret_cast<const float4 *>(mem + kR2 + 4 * lane);
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+          const float4 t = src[k];
+          W[2 * k] = V2(t.x, t.y); W[2 * k + 1] = V2(t.z, t.w);
         }
-      }
+        qmf_core_f32<2>(W, T, lo, hi);
+      } else { for (int d = 0; d < 2; d++) { lo[d] = mem[lane + d]; hi[d] = 1.0f; } }
+      if (lane < 46) S.d2[lane] = mem[kR2 + 256 + lane];
       if (lane < 48) {
         if (emit) {
           *reinterpret_cast<float2 *>(&mem[kR2 + 80 + 2 * lane]) = make_float2(lo[0], lo[1]);
           *reinterpret_cast<float2 *>(&mem[kR2 + 256 + 80 + 2 * lane]) = make_float2(hi[0], hi[1]);
         }
       } else {
+        // the last 32 samples of bands 0, 1 (encoder.js:309-316): windowed into this frame's input, and, with the
+        // mirrored window, kept in registers as the next frame's overlap, which these same lanes write then
         const int k = 2 * (lane - 48);
         const float wl0 = S.win[k], wl1 = S.win[k + 1], wh0 = S.win[31 - k], wh1 = S.win[30 - k];
-        *reinterpret_cast<float2 *>(&S.pre0[k]) = make_float2(wl0 * lo[0], wl1 * lo[1]);
-        *reinterpret_cast<float2 *>(&S.pre1[k]) = make_float2(wl0 * hi[0], wl1 * hi[1]);
         if (emit) {
+          *reinterpret_cast<float2 *>(&mem[kR2 + 48 + k]) = make_float2(ov0a, ov0b);
+          *reinterpret_cast<float2 *>(&mem[kR2 + 256 + 48 + k]) = make_float2(ov1a, ov1b);
           *reinterpret_cast<float2 *>(&mem[kR2 + 80 + 2 * lane]) = make_float2(lo[0] * wh0, lo[1] * wh1);
           *reinterpret_cast<float2 *>(&mem[kR2 + 256 + 80 + 2 * lane]) = make_float2(hi[0] * wh0, hi[1] * wh1);
         }
+        ov0a = wl0 * lo[0]; ov0b = wl1 * lo[1];
+        ov1a = wl0 * hi[0]; ov1b = wl1 * hi[1];
       }
     }
     const float W = __builtin_amdgcn_sqrtf(P + p_prev), Lw = __builtin_amdgcn_sqrtf(Q + q_prev);
@@ -298,72 +326,91 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     if (!emit) continue;
 
     // ---------------- long-block MDCT in binary32 ----------------
-    float2 x[4];
+    // position 4g + j of the lane holds point k_j = r + q * bitrev2(j): j = 1 -> 2q, j = 2 -> q, j = 3 -> 3q
+    // (the base values pass through an opaque asm once per frame: otherwise every address derived from them is
+    // loop invariant, gets hoisted out of the frame loop and spilled)
+    SpecBase B = B0;
+    asm volatile("" : "+v"(B.ia0), "+v"(B.ic0), "+v"(B.q2), "+v"(B.ib), "+v"(B.id), "+v"(B.pt0));
+    asm volatile("" : "+v"(B.za), "+v"(B.zb), "+v"(B.zc), "+v"(B.zd), "+v"(B.g));
+    asm volatile("" : "+v"(B.e0), "+v"(B.e1), "+v"(B.po0));
+    v2f x[4];
     float zrow;
     {
-      const float2 t0 = table_f2(RT, G.pre_tab[0]), t1 = table_f2(RT, G.pre_tab[1]);
-      const float2 t2 = table_f2(RT, G.pre_tab[2]), t3 = table_f2(RT, G.pre_tab[3]);
-      const float a0 = mem[G.ia[0]], c0 = mem[G.ic[0]], b0 = mem[G.ib0], d0 = mem[G.id0];
-      const float a1 = mem[G.ia[1]], c1 = mem[G.ic[1]];
-      const float a2 = mem[G.ia[2]], c2 = mem[G.ic[2]];
-      const float a3 = mem[G.ia[3]], c3 = mem[G.ic[3]], b3 = mem[G.ib3], d3 = mem[G.id3];
-      const float r0 = a0 + b0, m0 = c0 - d0;               // mdct.js:76-89
-      const float r3 = a3 - b3, m3 = c3 + d3;               // mdct.js:91-105; for positions 1, 2 the second operands are the zero padding
-      x[0] = make_float2(__builtin_fmaf(r0, t0.x, m0 * t0.y), __builtin_fmaf(m0, t0.x, -(r0 * t0.y)));
-      x[1] = make_float2(__builtin_fmaf(a1, t1.x, c1 * t1.y), __builtin_fmaf(c1, t1.x, -(a1 * t1.y)));
-      x[2] = make_float2(__builtin_fmaf(a2, t2.x, c2 * t2.y), __builtin_fmaf(c2, t2.x, -(a2 * t2.y)));
-      x[3] = make_float2(__builtin_fmaf(r3, t3.x, m3 * t3.y), __builtin_fmaf(m3, t3.x, -(r3 * t3.y)));
-      float en = x[0].x * x[0].x;
-      en = __builtin_fmaf(x[0].y, x[0].y, en);
+      const int qb = 4 * B.q2;                               // bytes between the pre-twiddle pairs of points q apart
+      const v2f t0 = table_f2(RT, B.pt0), t1 = table_f2(RT, B.pt0 + 2 * qb);
+      const v2f t2 = table_f2(RT, B.pt0 + qb), t3 = table_f2(RT, B.pt0 + 3 * qb);
+      const float a0 = mem[B.ia0], c0 = mem[B.ic0];
+      const float a1 = mem[B.ia0 - 2 * B.q2], c1 = mem[B.ic0 + 2 * B.q2];
+      const float a2 = mem[B.ia0 - B.q2], c2 = mem[B.ic0 + B.q2];
+      const float a3 = mem[B.ia0 - 3 * B.q2], c3 = mem[B.ic0 + 3 * B.q2];
+      const float bb = mem[B.ib], dd = mem[B.id];             // the lane's one pair outside the zero padding (or unused)
+      const float b0 = B.use_lo ? bb : 0.0f, d0 = B.use_lo ? dd : 0.0f;
+      const float b3 = B.use_hi ? bb : 0.0f, d3 = B.use_hi ? dd : 0.0f;
+      // (r, m) = (a + b, c - d) in the first half of the pre-twiddle (mdct.js:76-89), (a - b, c + d) in the second
+      // (:91-105); for positions 1, 2 the operands b, d are the zero padding.  Then (r c + m s, m c - r s).
+      const v2f rm0 = pk_fma(V2(b0, d0), PMN, V2(a0, c0)), rm3 = pk_fma(V2(b3, d3), PNM, V2(a3, c3));
+      const v2f rm1 = V2(a1, c1), rm2 = V2(a2, c2);
+      auto twiddle = [](v2f rm, v2f t) { const v2f u = rm.yx * (t.yy * PMN); return pk_fma(rm, t.xx, u); };   // u = (m s, -(r s))
+      x[0] = twiddle(rm0, t0); x[1] = twiddle(rm1, t1); x[2] = twiddle(rm2, t2); x[3] = twiddle(rm3, t3);
+      v2f en2 = x[0] * x[0];
 #pragma unroll
-      for (int j = 1; j < 4; j++) { en = __builtin_fmaf(x[j].x, x[j].x, en); en = __builtin_fmaf(x[j].y, x[j].y, en); }
-      zrow = row_allreduce(en);
+      for (int j = 1; j < 4; j++) en2 = pk_fma(x[j], x[j], en2);
+      zrow = row_allreduce(en2.x + en2.y);
       // stages 1, 2: twiddles 1 and -i, no products
-      const float2 u0 = x[0] + x[1], u1 = x[0] - x[1], u2 = x[2] + x[3], u3 = x[2] - x[3];
+      const v2f u0 = x[0] + x[1], u1 = x[0] - x[1], u2 = x[2] + x[3], u3 = x[2] - x[3];
       x[0] = u0 + u2;
       x[2] = u0 - u2;
-      x[1] = make_float2(u1.x + u3.y, u1.y - u3.x);
-      x[3] = make_float2(u1.x - u3.y, u1.y + u3.x);
+      x[1] = pk_fma(u3.yx, PMN, u1);
+      x[3] = pk_fma(u3.yx, PNM, u1);
     }
-    float2 *z = reinterpret_cast<float2 *>(mem);
+    v2f *z = reinterpret_cast<v2f *>(mem);
     {
-      float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+      float4 *dst = reinterpret_cast<float4 *>(z + B.za);
       dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
       dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
     }
-    const float2 wBa = table_f2(RT, G.twb), wBb = table_f2(RT, G.twb + 8), wBc = table_f2(RT, G.twb + 16);
+    const int twb = (int)offsetof(C1DevTables, r4b) + 24 * (B.g & 3);
+    const v2f wBa = table_f2(RT, twb), wBb = table_f2(RT, twb + 8), wBc = table_f2(RT, twb + 16);
     __syncthreads();
     {
-      float2 *p = z + G.zb;
+      v2f *p = z + B.zb;
       x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
       radix4_round(x, wBa, wBb, wBc);
       p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3];
     }
-    const float2 wCa = table_f2(RT, G.twc), wCb = table_f2(RT, G.twc + 8), wCc = table_f2(RT, G.twc + 16);
-    const float2 wDa = table_f2(RT, G.twd), wDb = table_f2(RT, G.twd + 256);
+    const int twc = (int)offsetof(C1DevTables, r4c) + 24 * (B.g & 15), twd = (int)offsetof(C1DevTables, r2d) + 8 * (B.g & 31);
+    const v2f wCa = table_f2(RT, twc), wCb = table_f2(RT, twc + 8), wCc = table_f2(RT, twc + 16);
+    const v2f wDa = table_f2(RT, twd), wDb = table_f2(RT, twd + 256);
     __syncthreads();
     {
-      float2 *p = z + G.zc;
+      v2f *p = z + B.zc;
       x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
       radix4_round(x, wCa, wCb, wCc);
-      if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
+      if (B.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
     }
-    const float2 p0 = table_f2(RT, G.post_tab[0]), p1 = table_f2(RT, G.post_tab[1]);
-    const float2 p2 = table_f2(RT, G.post_tab[2]), p3 = table_f2(RT, G.post_tab[3]);
+    // final points: bands 0/1 hold g + 16 j after round C; band 2 holds g, g + 64, g + 32, g + 96 after round D
+    const int d1 = B.band2 ? 64 : 16, d2 = 32, d3 = B.band2 ? 96 : 48;
+    const v2f p0 = table_f2(RT, B.po0), p1 = table_f2(RT, B.po0 + 8 * d1);
+    const v2f p2 = table_f2(RT, B.po0 + 8 * d2), p3 = table_f2(RT, B.po0 + 8 * d3);
     __syncthreads();
-    if (G.band2) {
-      const float2 *p = z + G.zd;
+    if (B.band2) {
+      const v2f *p = z + B.zd;
       x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
-      const float2 y1 = cmul32(x[1], wDa), y3 = cmul32(x[3], wDb);
-      const float2 e0 = x[0], e2 = x[2];
+      const v2f y1 = cmul32(x[1], wDa), y3 = cmul32(x[3], wDb);
+      const v2f e0 = x[0], e2 = x[2];
       x[0] = e0 + y1; x[1] = e0 - y1; x[2] = e2 + y3; x[3] = e2 - y3;
     }
     float *coef = mem + kR2;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const float2 t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
-      coef[G.cx[j]] = -__builtin_fmaf(x[j].x, t.x, x[j].y * t.y);            // mdct.js:110-119
-      coef[G.cy[j]] = __builtin_fmaf(x[j].y, t.x, -(x[j].x * t.y));
+      const v2f t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
+      const int dj = j == 0 ? 0 : (j == 1 ? d1 : (j == 2 ? d2 : d3));
+      const int e0 = B.e0 + 2 * dj, e1 = B.e1 - 2 * dj;      // bands 1 and 2 are stored reversed (utils.js:42-48)
+      // mdct.js:110-119: out[2 i] = -(re c + im s), out[n2 - 1 - 2 i] = im c - re s
+      const v2f u = x[j].yx * (t.yy * PMN);                  // (im s, -(re s))
+      const v2f o = pk_fma(x[j], t.xx, u);
+      coef[B.band0 ? e0 : e1] = -o.x;
+      coef[B.band0 ? e1 : e0] = o.y;
     }
     __syncthreads();
 
@@ -384,6 +431,8 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     const float e2 = __builtin_fmaf(T->spec_cz[2], Z2, __builtin_fmaf(T->spec_cw[2], W, __builtin_fmaf(T->spec_cl[2], Lw, eabs)));
     bool unstable;
     {
+      SfLong SFL = SFL0;
+      asm volatile("" : "+v"(SFL.src), "+v"(SFL.cnt));
       const float *src = coef + SFL.src;
       float mx = 0.0f;
 #pragma unroll
@@ -418,7 +467,10 @@ void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const ui
   hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, (unsigned long long)units, redo_count);
 }
 
-void c1k_launch_analysis_spec(const C1EncodeLaunch &L, hipStream_t stream) {
-  const int64_t runs = (L.frames + kRunFramesLong - 1) / kRunFramesLong;
+void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_analysis_spec);
+  C1EncodeLaunch L = L0;
+  L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
   hipLaunchKernelGGL(k_analysis_spec, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
 }

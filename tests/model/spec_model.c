@@ -121,22 +121,21 @@ static void mdct_long_f32(const float *in, int N, float *out, float *lane_energy
   for (int g = 0; g < lanes; g++) {
     const int r = bitrev(g, bits - 2), q = nfft / 4;
     f2 x[4];
-    float en = 0;
+    float enx = 0, eny = 0;
     for (int j = 0; j < 4; j++) {
       const int jp = ((j & 1) << 1) | (j >> 1);
       const int k = r + q * jp, i = 2 * k;
       float rr, mm;
       if (i < n4) { rr = in[n34 - 1 - i] + in[n34 + i]; mm = in[n4 + i] - in[n4 - 1 - i]; }
       else { rr = in[n34 - 1 - i] - in[i - n4]; mm = in[n4 + i] + in[5 * n4 - 1 - i]; }
-      /* the kernel skips the additions whose second operand is the structural zero padding (j = 1, 2): x + 0 == x
-       * except for x = -0, whose sign is irrelevant here; the model adds, and compares coefficients by value */
+      /* the kernel takes 0 for the operands that are structural zero padding instead of reading them: same values */
       const f2 t = pre[k];
       x[j].x = fmaf(rr, t.x, mm * t.y);
       x[j].y = fmaf(mm, t.x, -(rr * t.y));
-      en = j == 0 ? x[j].x * x[j].x : fmaf(x[j].x, x[j].x, en);
-      en = fmaf(x[j].y, x[j].y, en);
+      enx = j == 0 ? x[j].x * x[j].x : fmaf(x[j].x, x[j].x, enx);
+      eny = j == 0 ? x[j].y * x[j].y : fmaf(x[j].y, x[j].y, eny);
     }
-    lane_energy[g] = en;
+    lane_energy[g] = enx + eny;
     /* stages 1, 2 without products */
     const f2 t0 = cadd(x[0], x[1]), t1 = csub(x[0], x[1]), t2 = cadd(x[2], x[3]), t3 = csub(x[2], x[3]);
     f2 y1 = {t1.x + t3.y, t1.y - t3.x}, y3 = {t1.x - t3.y, t1.y + t3.x};
@@ -175,19 +174,21 @@ void spec_model_frame(spec_state *s, const float *pcm, float *coefs, float *eps,
   memcpy(w1 + 46, pcm, 512 * sizeof(float));
   for (int l = 0; l < 64; l++) {
     const float *a = pcm + 4 * l, *b = pcm + 256 + 4 * l;
-    float p = a[0] * a[0];
-    p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
-    p = fmaf(b[0], b[0], p); p = fmaf(b[1], b[1], p); p = fmaf(b[2], b[2], p); p = fmaf(b[3], b[3], p);
-    lane[l] = p;
+    /* packed: two running sums, (x, y) halves of the 2-vectors the kernel squares */
+    float px = a[0] * a[0], py = a[1] * a[1];
+    px = fmaf(a[2], a[2], px); py = fmaf(a[3], a[3], py);
+    px = fmaf(b[0], b[0], px); py = fmaf(b[1], b[1], py);
+    px = fmaf(b[2], b[2], px); py = fmaf(b[3], b[3], py);
+    lane[l] = px + py;
   }
   const float P = wave_sum(lane);
   for (int i = 0; i < 256; i++) qmf_pair(w1 + 2 * i, &low1[i], &high1[i]);
   memcpy(s->d1, w1 + 512, sizeof s->d1);
   for (int l = 0; l < 64; l++) {
     const float *a = low1 + 4 * l;
-    float p = a[0] * a[0];
-    p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
-    lane[l] = p;
+    float px = a[0] * a[0], py = a[1] * a[1];
+    px = fmaf(a[2], a[2], px); py = fmaf(a[3], a[3], py);
+    lane[l] = px + py;
   }
   const float Q = wave_sum(lane);
   memcpy(w2, s->d2, sizeof s->d2);
