@@ -74,6 +74,8 @@ SIGNATURES = {
     'c1_encode_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                           C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    'c1_detect_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
+                                          C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p]),
     'c1_spec_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                         C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
 }

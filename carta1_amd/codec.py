@@ -182,6 +182,8 @@ class Context:
         samples = buf.size // (bps * channels)
         frames = (samples + 511) // 512
         units = out if out is not None else np.zeros((frames * channels, 212), dtype=np.uint8)
+        if units.dtype != np.uint8 or not units.flags['C_CONTIGUOUS'] or units.size != frames * channels * 212:
+            raise ValueError('out must be a contiguous uint8 array of frames * channels * 212 bytes')
         capi.check(capi.load().c1_encode_wav_batch(self._h, buf.ctypes.data, bits, channels, samples, C.byref(opts), units.ctypes.data))
         return units.reshape(-1, 212)
 
@@ -190,6 +192,8 @@ class Context:
         u = np.ascontiguousarray(units, dtype=np.uint8).reshape(-1, 212)
         frames = u.shape[0] // channels
         pcm = out if out is not None else np.zeros((frames * 512, channels), dtype=np.int16)
+        if pcm.dtype != np.int16 or not pcm.flags['C_CONTIGUOUS'] or pcm.size != frames * 512 * channels:
+            raise ValueError('out must be a contiguous int16 array of frames * 512 * channels samples')
         capi.check(capi.load().c1_decode_wav16_batch(self._h, u.ctypes.data, channels, frames, pcm.ctypes.data))
         return pcm
 
@@ -205,6 +209,13 @@ class Context:
         capi.check(capi.load().c1_encode_stages_device(
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
             C.c_void_p(bands_ptr), C.c_void_p(coefs_ptr), C.c_void_p(side_ptr), C.c_void_p(alloc_ptr)))
+
+    def detect_stages_device(self, pcm_ptrs, frames, mags_ptr, modes_ptr, options=None, halo_frames=0):
+        """The transient detector's magnitude spectra (256 floats per unit) and chosen block modes (1 byte per unit)."""
+        opts = (options or EncoderOptions()).to_c()
+        capi.check(capi.load().c1_detect_stages_device(
+            self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
+            C.c_void_p(mags_ptr), C.c_void_p(modes_ptr)))
 
     def spec_stages_device(self, pcm_ptrs, frames, coefs_ptr, eps_ptr, side_ptr, options=None, halo_frames=0):
         """The speculative binary32 analysis alone: coefficients, their proven error bounds, scale-factor indices."""

@@ -225,7 +225,45 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
 }
 
 // rank table of the Float32 heap priorities (bitallocation.js:226-231, 267-269)
+int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d);
+// The rank tables depend on the biased scale factors only, and the search for an integer form costs ~30 M host
+// operations when there is none: keep the last few results.
 int build_encode_opts(const c1_encode_options &o, C1DevEncOpts *d) {
+  struct Entry { double biased[64]; C1DevEncOpts opts; };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry &e : cache)
+      if (memcmp(e.biased, o.biased_scale_factors, sizeof e.biased) == 0) {
+        C1DevEncOpts probe;                          // the validation of the other fields, without the rank search
+        *d = e.opts;
+        if (std::isnan(o.transient_threshold)) return fail(C1_ERR_ARG, "transient_threshold is NaN");
+        d->threshold = o.transient_threshold;
+        const bool detect = o.fixed_block_modes[0] < 0;
+        for (int b = 0; b < 3; b++) {
+          const int m = o.fixed_block_modes[b];
+          if (detect) { d->modes[b] = -1; continue; }
+          if (m < 0 || m > (b == 2 ? 3 : 2))
+            return fail(C1_ERR_ARG, "fixed_block_modes[%d] = %d is outside 0..%d", b, m, b == 2 ? 3 : 2);
+          d->modes[b] = m;
+        }
+        (void)probe;
+        return C1_OK;
+      }
+  }
+  const int rc = build_encode_opts_uncached(o, d);
+  if (rc == C1_OK) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    Entry e;
+    memcpy(e.biased, o.biased_scale_factors, sizeof e.biased);
+    e.opts = *d;
+    cache.push_back(e);
+  }
+  return rc;
+}
+int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
   memset(d, 0, sizeof *d);
   for (int i = 0; i < 64; i++) {
     if (!std::isfinite(o.biased_scale_factors[i]) || o.biased_scale_factors[i] < 0)
@@ -287,6 +325,8 @@ int build_encode_opts(const c1_encode_options &o, C1DevEncOpts *d) {
   return C1_OK;
 }
 
+constexpr int64_t kMaxChunkFrames = (int64_t)1 << 27;   // x 2 channels = 2^28 units per chunk < 2^29
+
 struct Timing {
   hipEvent_t start, stop;
   int kind;
@@ -297,6 +337,10 @@ const char *const kKindNames[K_KINDS] = {"analysis", "allocate", "pack", "decode
 }  // namespace
 
 struct c1_ctx {
+  // Every public entry point that touches the context holds this for its whole duration: calls on one context are
+  // serialised on the host (workspace, staging buffers, option cache and timings are per context), as the GPU side
+  // already is by the context's stream.  Recursive because entry points call each other (batch -> device, ...).
+  std::recursive_mutex mu;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -331,6 +375,7 @@ struct c1_ctx {
   hipStream_t s_ana = nullptr, s_rest = nullptr;  // internal streams of the two pipeline halves
   hipEvent_t ev_in = nullptr, ev_ana[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
   // profiling
+  int timing_depth = 0;                          // > 0 inside a multi-chunk host call: the per-chunk device calls keep the timings
   bool profiling = false;
   std::vector<Timing> timings;
   std::vector<hipEvent_t> event_pool;
@@ -347,6 +392,10 @@ struct c1_ctx {
 };
 
 namespace {
+
+#define CTX_GUARD(c)                                   \
+  std::unique_lock<std::recursive_mutex> ctx_guard_;   \
+  if (c) ctx_guard_ = std::unique_lock<std::recursive_mutex>((c)->mu)
 
 int ctx_bind(c1_ctx *ctx) {
   if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
@@ -492,6 +541,7 @@ int check_channels(int channels) {
 int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                        const c1_encode_options *opts, uint8_t *units, float *bands, float *coefs_tap,
                        uint8_t *side_tap, uint8_t *alloc_tap) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -503,7 +553,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     if ((uintptr_t)pcm[c] & 15) return fail(C1_ERR_ARG, "pcm[%d] must be 16-byte aligned on the device", c);
   }
   if ((rc = upload_opts(ctx, opts))) return rc;
-  if (ctx->profiling) reset_timings(ctx);
+  if (ctx->profiling && ctx->timing_depth == 0) reset_timings(ctx);
   if (frames == 0) return C1_OK;
   const bool detect = opts->fixed_block_modes[0] < 0;
   const int64_t chunk = ctx->chunk_frames;
@@ -511,6 +561,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   if ((rc = ensure_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (detect && (rc = ensure_detect_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (taps && (!coefs_tap || !side_tap || !alloc_tap)) return fail(C1_ERR_ARG, "coefs, side and alloc taps must be given together");
+  if (taps && frames > kMaxChunkFrames) return fail(C1_ERR_ARG, "stage taps are not chunked: at most %lld frames per call", (long long)kMaxChunkFrames);
   // Two-stage software pipeline over chunks: the analysis of chunk i+1 (fp64-VALU bound) runs on one
   // stream while allocation + packing of chunk i (latency bound) run on another, each chunk on its own
   // half of the workspace.  Everything is ordered after the caller's stream and joined back into it.
@@ -750,6 +801,9 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   const char *env = getenv("C1_CHUNK_FRAMES");
   ctx->chunk_frames = env ? atoll(env) : 524288;
   if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
+  // the allocation work list packs (unit << 3 | candidate) into 32 bits and unit lists are 32-bit: a chunk holds
+  // fewer than 2^29 units, with room to spare
+  if (ctx->chunk_frames > kMaxChunkFrames) ctx->chunk_frames = kMaxChunkFrames;
   *out = ctx;
   return C1_OK;
 }
@@ -788,6 +842,7 @@ int c1_ctx_destroy(c1_ctx *ctx) {
 }
 
 int c1_ctx_synchronize(c1_ctx *ctx) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -796,6 +851,7 @@ int c1_ctx_synchronize(c1_ctx *ctx) {
 
 int c1_ctx_set_profiling(c1_ctx *ctx, int enabled) {
   if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
+  CTX_GUARD(ctx);
   ctx->profiling = enabled != 0;
   return C1_OK;
 }
@@ -803,6 +859,7 @@ int c1_ctx_set_profiling(c1_ctx *ctx, int enabled) {
 int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
   if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
   if (mode < 0 || mode > 2) return fail(C1_ERR_ARG, "speculation mode must be 0, 1 or 2, got %d", mode);
+  CTX_GUARD(ctx);
   ctx->spec_mode = mode;
   ctx->spec_last_fraction = 0.0;
   ctx->spec_exact_calls = 0;
@@ -810,6 +867,7 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
 }
 
 int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   unsigned long long tot[2] = {0, 0};
@@ -825,6 +883,7 @@ int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int
 }
 
 int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if (!name || !ms) return fail(C1_ERR_ARG, "name or ms is NULL");
@@ -860,8 +919,40 @@ int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, nullptr, bands, coefs, side, alloc);
 }
 
+int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                            const c1_encode_options *opts, float *mags, uint8_t *modes) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
+  if (!pcm || !opts) return fail(C1_ERR_ARG, "NULL argument");
+  if (opts->fixed_block_modes[0] >= 0) return fail(C1_ERR_ARG, "the detector taps need transient detection (fixed_block_modes -1)");
+  if (frames > kMaxChunkFrames) return fail(C1_ERR_ARG, "stage taps are not chunked: at most %lld frames per call", (long long)kMaxChunkFrames);
+  for (int c = 0; c < channels; c++)
+    if (!pcm[c] || ((uintptr_t)pcm[c] & 15)) return fail(C1_ERR_ARG, "pcm[%d] must be a 16-byte aligned device pointer", c);
+  if ((rc = upload_opts(ctx, opts))) return rc;
+  if (frames == 0) return C1_OK;
+  const int64_t units = frames * channels;
+  if ((rc = ensure_workspace(ctx, units))) return rc;
+  if ((rc = ensure_detect_workspace(ctx, units))) return rc;
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c];
+  L.channels = channels; L.frames = frames; L.halo_frames = halo_frames;
+  L.tables = ctx->d_tables; L.opts = ctx->d_opts;
+  L.coefs = ctx->d_coefs[0]; L.side = ctx->d_side[0]; L.alloc = ctx->d_alloc[0]; L.cand = ctx->d_cand[0];
+  L.work_count = ctx->d_work[0]; L.work_list = ctx->d_work[0] + 4;
+  L.mags = mags;
+  c1k_launch_detect(L, ctx->d_bands[0], ctx->d_feat[0], ctx->d_modes[0], ctx->d_lists[0], ctx->stream);
+  if (modes) HIP_TRY(hipMemcpyAsync(modes, ctx->d_modes[0], (size_t)units, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
 int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                           const c1_encode_options *opts, float *coefs, float *eps, uint8_t *side) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -915,10 +1006,16 @@ int ensure_ring(c1_ctx *ctx, size_t bytes) {
   return C1_OK;
 }
 
-// Leaves no copy in flight into or out of the caller's host memory, whichever way the function returns.
+// Leaves no copy in flight into or out of the caller's host memory, whichever way the function returns.  While it
+// lives, the per-chunk device calls add to the context's kernel timings instead of restarting them.
 struct StreamDrain {
   c1_ctx *ctx;
+  explicit StreamDrain(c1_ctx *c) : ctx(c) {
+    if (ctx->profiling && ctx->timing_depth == 0) reset_timings(ctx);
+    ctx->timing_depth++;
+  }
   ~StreamDrain() {
+    ctx->timing_depth--;
     if (ctx->s_up) (void)hipStreamSynchronize(ctx->s_up);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->s_down) (void)hipStreamSynchronize(ctx->s_down);
@@ -936,7 +1033,7 @@ int encode_batch_streamed(c1_ctx *ctx, const float *const *pcm, int channels, in
   const size_t set_bytes = in_bytes * channels + out_bytes;
   int rc = ensure_ring(ctx, 2 * set_bytes);
   if (rc) return rc;
-  StreamDrain drain{ctx};
+  StreamDrain drain(ctx);
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
     const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
@@ -984,7 +1081,7 @@ int decode_batch_streamed(c1_ctx *ctx, const uint8_t *units, int channels, int64
   const size_t set_bytes = in_bytes + out_bytes * channels;
   int rc = ensure_ring(ctx, 2 * set_bytes);
   if (rc) return rc;
-  StreamDrain drain{ctx};
+  StreamDrain drain(ctx);
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
     const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
@@ -1042,6 +1139,7 @@ int c1_host_free(void *p) {
 
 int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                     const c1_encode_options *opts, uint8_t *units) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -1074,12 +1172,13 @@ int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t 
 
 int c1_decode_device(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int halo_units,
                      float *const *pcm) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
   if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
   if (halo_units < 0 || halo_units > 1) return fail(C1_ERR_ARG, "halo_units must be 0 or 1");
-  if (ctx->profiling) reset_timings(ctx);
+  if (ctx->profiling && ctx->timing_depth == 0) reset_timings(ctx);
   if (frames == 0) return C1_OK;
   if (!units || !pcm) return fail(C1_ERR_ARG, "units or pcm is NULL");
   if ((uintptr_t)units & 3) return fail(C1_ERR_ARG, "units must be 4-byte aligned on the device");
@@ -1102,6 +1201,7 @@ int c1_decode_device(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fr
 
 int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int halo_units,
                     float *const *pcm) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -1133,6 +1233,7 @@ int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fra
 // ---- WAV body <-> units in one host call (streamed) -----------------------------------------------------------------
 int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int channels, int64_t samples_per_channel,
                         const c1_encode_options *opts, uint8_t *units) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -1147,7 +1248,7 @@ int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int chan
   const size_t out_bytes = ((size_t)chunk * channels * C1_UNIT_BYTES + 255) & ~(size_t)255;
   const size_t set_bytes = raw_bytes + pcm_bytes * channels + out_bytes;
   if ((rc = ensure_ring(ctx, 2 * set_bytes))) return rc;
-  StreamDrain drain{ctx};
+  StreamDrain drain(ctx);
   const uint8_t *src = static_cast<const uint8_t *>(interleaved);
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
@@ -1195,6 +1296,7 @@ int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int chan
 }
 
 int c1_decode_wav16_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t frames, int16_t *interleaved) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -1207,7 +1309,7 @@ int c1_decode_wav16_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64
   const size_t out_bytes = (size_t)chunk * 512 * channels * sizeof(int16_t);
   const size_t set_bytes = in_bytes + pcm_bytes * channels + out_bytes;
   if ((rc = ensure_ring(ctx, 2 * set_bytes))) return rc;
-  StreamDrain drain{ctx};
+  StreamDrain drain(ctx);
   auto download = [&](int64_t index) -> int {
     const int p = (int)(index & 1);
     const int64_t f0 = index * chunk, n = std::min(chunk, frames - f0);
@@ -1260,6 +1362,7 @@ struct c1_enc_stream {
 };
 
 int c1_enc_stream_create(c1_ctx *ctx, int channels, const c1_encode_options *opts, c1_enc_stream **out) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if (!out || !opts) return fail(C1_ERR_ARG, "out or opts is NULL");
@@ -1279,6 +1382,7 @@ int c1_enc_stream_create(c1_ctx *ctx, int channels, const c1_encode_options *opt
 int c1_enc_stream_push(c1_enc_stream *s, const float *const *pcm, int64_t frames, uint8_t *units) {
   if (!s) return fail(C1_ERR_ARG, "stream is NULL");
   c1_ctx *ctx = s->ctx;
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
@@ -1331,6 +1435,7 @@ struct c1_dec_stream {
 };
 
 int c1_dec_stream_create(c1_ctx *ctx, int channels, c1_dec_stream **out) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if (!out) return fail(C1_ERR_ARG, "out is NULL");
@@ -1346,6 +1451,7 @@ int c1_dec_stream_create(c1_ctx *ctx, int channels, c1_dec_stream **out) {
 int c1_dec_stream_push(c1_dec_stream *s, const uint8_t *units, int64_t frames, float *const *pcm) {
   if (!s) return fail(C1_ERR_ARG, "stream is NULL");
   c1_ctx *ctx = s->ctx;
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
@@ -1388,6 +1494,7 @@ int c1_dec_stream_destroy(c1_dec_stream *s) {
 // ---- formats either side of the path ---------------------------------------------------------------------
 int c1_pcm_from_int_device(c1_ctx *ctx, const void *interleaved, int bits, int channels, int64_t samples_per_channel,
                            float *const *pcm) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -1402,6 +1509,7 @@ int c1_pcm_from_int_device(c1_ctx *ctx, const void *interleaved, int bits, int c
 
 int c1_pcm_to_int16_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t samples_per_channel,
                            int16_t *interleaved) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
@@ -1431,6 +1539,7 @@ int c1_aea_header(const char *title, uint32_t unit_count, int channels, uint8_t 
 
 // ---- synthetic input ----------------------------------------------------------------------------------
 int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, float *pcm) {
+  CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");

@@ -85,6 +85,7 @@ struct C1EncodeLaunch {
   uint32_t *work_list;   // frames*channels*7 entries (unit<<3 | candidate)
   uint32_t *work_count;
   float *bands;      // optional tap (may be null)
+  float *mags;       // optional tap of the transient detector's magnitude spectra, frames*channels*256 (64 | 64 | 128)
   uint8_t *units;    // frames*channels*212   (may be null for stage taps)
   // speculative binary32 path
   float *eps;            // frames*channels*kEpsFloats: per-band bound on |binary32 coefficient - reference coefficient|

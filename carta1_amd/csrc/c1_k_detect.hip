@@ -230,6 +230,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
       }
     }
     __syncthreads();                                           // the per-bin terms reuse the memory of the points
+    if (L.mags && f >= f0) {                                   // stage tap: performFFT's magnitudes (transient.js:17-35)
+#pragma unroll
+      for (int i = 0; i < 4; i++) L.mags[((f * L.channels + ch) << 8) + t_mag + i * tS] = mg[i];
+    }
     if (emit) {
       // ---------------- feature terms per bin, then the reference's sequential sums ----------------
       bool valid[4];

@@ -391,6 +391,12 @@ napi_value EncodeBatchAsync(napi_env env, napi_callback_info info) {
   j->frames = (int64_t)(samples / 512) - halo;
   for (size_t c = 0; c < ch.size(); c++) j->in[c] = ch[c] + (size_t)halo * 512;
   napi_value out = make_u8(env, (size_t)j->frames * ch.size() * C1_UNIT_BYTES, &j->units_out);
+  if (!out || (j->frames > 0 && !j->units_out)) {
+    delete j;
+    napi_throw_error(env, nullptr, "could not allocate the result");
+    return nullptr;
+  }
+  napi_create_reference(env, argv[0], 1, &j->keep[j->nkeep++]);   // the context must outlive the job
   napi_create_reference(env, argv[1], 1, &j->keep[j->nkeep++]);
   napi_create_reference(env, out, 1, &j->result);
   return start_job(env, j, "carta1.encodeBatch");
@@ -421,8 +427,14 @@ napi_value DecodeBatchAsync(napi_env env, napi_callback_info info) {
   napi_create_array_with_length(env, channels, &arr);
   for (int c = 0; c < channels; c++) {
     napi_value ta = make_f32(env, (size_t)j->frames * 512, &j->outp[c]);
+    if (!ta || (j->frames > 0 && !j->outp[c])) {
+      delete j;
+      napi_throw_error(env, nullptr, "could not allocate the result");
+      return nullptr;
+    }
     napi_set_element(env, arr, c, ta);
   }
+  napi_create_reference(env, argv[0], 1, &j->keep[j->nkeep++]);   // the context must outlive the job
   napi_create_reference(env, argv[1], 1, &j->keep[j->nkeep++]);
   napi_create_reference(env, arr, 1, &j->result);
   return start_job(env, j, "carta1.decodeBatch");

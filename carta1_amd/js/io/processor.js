@@ -87,7 +87,16 @@ export function decodeAeaToWav16(bytes) {
   const { info, units } = AudioProcessor.parseAea(bytes)
   const nch = info.channelCount
   if (nch !== 1 && nch !== 2) throw new Error(`Unsupported channel count: ${nch}`)
-  const whole = units.subarray(0, units.length - (units.length % (nch * SOUND_UNIT_SIZE)))
+  // a stereo image that ends on a lone left unit: the reference pairs it with a dummy right unit (processor.js:222-232)
+  let whole = units
+  const rest = units.length % (nch * SOUND_UNIT_SIZE)
+  if (rest >= SOUND_UNIT_SIZE) {
+    whole = new Uint8Array(units.length - rest + nch * SOUND_UNIT_SIZE)
+    whole.set(units.subarray(0, units.length - rest + SOUND_UNIT_SIZE))
+    whole[units.length - rest + SOUND_UNIT_SIZE] = 0xac            // the dummy unit's two header bytes, zeros after
+  } else if (rest) {
+    whole = units.subarray(0, units.length - rest)
+  }
   return { channelCount: nch, samples: whole.length ? native().decodeWav16Batch(context(), whole, nch) : new Int16Array(0) }
 }
 

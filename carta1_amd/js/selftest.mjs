@@ -148,6 +148,34 @@ async function main() {
       }
       ok(same, 'decodeAeaToWav16 == decodeAeaPcm + the 16-bit conversion of createWavBlob')
     }
+    // two un-awaited encodes on the shared context (libuv pool threads): each must equal its sequential result
+    {
+      const a = [white(41, 300 * 512), white(42, 300 * 512)], b = [pinkT(43, 300 * 512), pinkT(44, 300 * 512)]
+      const seqA = await c1.encodeAeaPcm(a, { fixedBlockModes: [0, 0, 0] })
+      const seqB = await c1.encodeAeaPcm(b, {})
+      const [parA, parB, parA2] = await Promise.all([c1.encodeAeaPcm(a, { fixedBlockModes: [0, 0, 0] }), c1.encodeAeaPcm(b, {}),
+                                                     c1.encodeAeaPcm(a, { fixedBlockModes: [0, 0, 0] })])
+      ok(hex(seqA) === hex(parA) && hex(seqB) === hex(parB) && hex(seqA) === hex(parA2), 'Promise.all of encodes on one context == sequential results')
+      const [pa, pb] = await Promise.all([c1.decodeAeaPcm(seqA), c1.decodeAeaPcm(seqB)])
+      const sa = await c1.decodeAeaPcm(seqA), sb = await c1.decodeAeaPcm(seqB)
+      const same = (x, y) => Buffer.from(x.buffer, x.byteOffset, x.byteLength).equals(Buffer.from(y.buffer, y.byteOffset, y.byteLength))
+      ok(same(pa[0], sa[0]) && same(pa[1], sa[1]) && same(pb[0], sb[0]) && same(pb[1], sb[1]), 'Promise.all of decodes on one context == sequential results')
+    }
+    // a stereo image that ends on a lone left unit: both decode entry points pair it with the dummy unit
+    {
+      const img = await c1.encodeAeaPcm([white(51, 3 * 512), white(52, 3 * 512)], {})
+      const odd = img.slice(0, img.length - 212)
+      const pcm = await c1.decodeAeaPcm(odd)
+      const w16 = c1.decodeAeaToWav16(odd)
+      let same = pcm[0].length === 3 * 512 && w16.samples.length === 3 * 512 * 2
+      for (let i = 0; same && i < pcm[0].length; i++) {
+        for (let c = 0; c < 2; c++) {
+          const x = Math.max(-1, Math.min(1, pcm[c][i]))
+          if (w16.samples[2 * i + c] !== ((x < 0 ? x * 0x8000 : x * 0x7fff) | 0)) same = false
+        }
+      }
+      ok(same, 'odd unit count: decodeAeaToWav16 == decodeAeaPcm (dummy right unit)')
+    }
     // page-locked PCM: a batch of more than one streaming chunk (32768 frames) must give the same bytes
     {
       const nf = 40000, plain = white(21, nf * 512)

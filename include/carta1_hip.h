@@ -199,6 +199,13 @@ int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
                             int halo_frames, const c1_encode_options *opts, float *bands,
                             float *coefs, uint8_t *side, uint8_t *alloc /* frames*channels*32 or NULL */);
 
+/* Stage taps of the transient detector (transient.js:17-226, blockSelectorStage encoder.js:111-152), device pointers:
+ * mags:  frames*channels*256 floats, performFFT's magnitude spectra of the three bands (64 | 64 | 128 per unit index);
+ * modes: frames*channels bytes, the block modes the detector chose (m0 | m1<<2 | m2<<4).  opts must ask for detection
+ * (fixed_block_modes {-1,-1,-1}).  Either pointer may be NULL. */
+int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                            const c1_encode_options *opts, float *mags, uint8_t *modes);
+
 /* The speculative binary32 analysis on its own (diagnostics; tests/test_gpu_spec.py checks the bound with it):
  * coefs: frames*channels*512 floats = the binary32 coefficients; eps: frames*channels*4 floats = the proven bound on
  * |coefficient - reference coefficient| for bands 0, 1, 2 and a flag word (non-zero bit pattern: a scale-factor
