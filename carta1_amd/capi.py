@@ -14,6 +14,8 @@ FRAME = 512
 UNIT_BYTES = 212
 SIGNAL_WHITE = 0
 SIGNAL_PINK_BURSTS = 1
+SIGNAL_MIXED = 2
+SIGNAL_PARTIALS = 3
 
 
 class Carta1Error(RuntimeError):

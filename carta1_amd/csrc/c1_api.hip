@@ -1546,30 +1546,42 @@ int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, f
   if (frames == 0) return C1_OK;
   if (!pcm || ((uintptr_t)pcm & 15)) return fail(C1_ERR_ARG, "pcm must be a 16-byte aligned device pointer");
   if (seed == 0) return fail(C1_ERR_ARG, "xorshift32 seed must be non-zero");
-  std::vector<uint32_t> states;
-  if (signal == C1_SIGNAL_WHITE) {
+  if (signal != C1_SIGNAL_WHITE && signal != C1_SIGNAL_PINK_BURSTS && signal != C1_SIGNAL_MIXED && signal != C1_SIGNAL_PARTIALS) return fail(C1_ERR_ARG, "unknown signal %d", signal);
+  std::vector<uint32_t> white_states, pink_states;
+  if (signal == C1_SIGNAL_WHITE || signal == C1_SIGNAL_MIXED) {
     // one draw per sample: state before frame f = T^(512 f) seed
     const XsMatrix jump = xs_power(512);
-    states.resize((size_t)frames);
+    white_states.resize((size_t)frames);
     uint32_t s = seed;
-    for (int64_t f = 0; f < frames; f++) { states[(size_t)f] = s; s = jump.apply(s); }
-  } else if (signal == C1_SIGNAL_PINK_BURSTS) {
+    for (int64_t f = 0; f < frames; f++) { white_states[(size_t)f] = s; s = jump.apply(s); }
+  }
+  if (signal == C1_SIGNAL_PINK_BURSTS || signal == C1_SIGNAL_MIXED) {
     // 512-frame segments; per 8 frames the generator draws 8*512 + 256 values, so the PRNG state at the
     // start of every segment is the exact continuation; the integrator restarts from 0 there
     const int64_t segs = (frames + 511) / 512;
     const XsMatrix jump = xs_power(64ull * (8 * 512 + 256));
-    states.resize((size_t)segs);
+    pink_states.resize((size_t)segs);
     uint32_t s = seed;
-    for (int64_t k = 0; k < segs; k++) { states[(size_t)k] = s; s = jump.apply(s); }
-  } else {
-    return fail(C1_ERR_ARG, "unknown signal %d", signal);
+    for (int64_t k = 0; k < segs; k++) { pink_states[(size_t)k] = s; s = jump.apply(s); }
   }
   uint32_t *d_states = nullptr;
-  HIP_TRY(hipMalloc(&d_states, states.size() * sizeof(uint32_t)));
-  hipError_t e = hipMemcpy(d_states, states.data(), states.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  const size_t nw = white_states.size(), np = pink_states.size();
+  HIP_TRY(hipMalloc(&d_states, (nw + np + 1) * sizeof(uint32_t)));
+  hipError_t e = hipSuccess;
+  if (nw) e = hipMemcpy(d_states, white_states.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && np) e = hipMemcpy(d_states + nw, pink_states.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    if (signal == C1_SIGNAL_WHITE) c1k_launch_generate_white(d_states, frames, pcm, ctx->stream);
-    else c1k_launch_generate_pink(d_states, frames, pcm, ctx->stream);
+    if (signal == C1_SIGNAL_WHITE) c1k_launch_generate_white(d_states, frames, pcm, 15, 0.5, ctx->stream);
+    else if (signal == C1_SIGNAL_PINK_BURSTS) c1k_launch_generate_pink(d_states + nw, frames, pcm, 15, ctx->stream);
+    else if (signal == C1_SIGNAL_PARTIALS) c1k_launch_generate_sines(frames, pcm, 15, seed, ctx->stream);
+    else {
+      // mixed corpus (BASELINE configs[3]): 512-frame segments cycling white noise / pink noise with bursts /
+      // stationary partials / quiet white noise
+      c1k_launch_generate_white(d_states, frames, pcm, 1, 0.5, ctx->stream);
+      c1k_launch_generate_pink(d_states + nw, frames, pcm, 2, ctx->stream);
+      c1k_launch_generate_sines(frames, pcm, 4, seed, ctx->stream);
+      c1k_launch_generate_white(d_states, frames, pcm, 8, 0.02, ctx->stream);
+    }
     e = hipStreamSynchronize(ctx->stream);
   }
   hipFree(d_states);

@@ -143,7 +143,9 @@ void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream)
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
 void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
-void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream);
-void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream);
+// kind_mask: bit k = fill the 512-frame segments with (segment & 3) == k (15 = all)
+void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, int kind_mask, double amp, hipStream_t stream);
+void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, int kind_mask, hipStream_t stream);
+void c1k_launch_generate_sines(int64_t frames, float *pcm, int kind_mask, uint32_t seed, hipStream_t stream);
 void c1k_launch_pcm_from_int(const void *src, int bits, int channels, int64_t n, float *const *pcm, hipStream_t stream);
 void c1k_launch_pcm_to_int16(const float *const *pcm, int channels, int64_t n, int16_t *dst, hipStream_t stream);

@@ -10,23 +10,40 @@ __device__ __forceinline__ double xorshift_u(uint32_t &s) {
   s ^= s << 13; s ^= s >> 17; s ^= s << 5;
   return ((double)s / 4294967296.0) * 2.0 - 1.0;
 }
-// one thread per frame; frame_states[f] = PRNG state before the frame's first sample
-__global__ void k_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm) {
+// one thread per frame; frame_states[f] = PRNG state before the frame's first sample.
+// kind_mask: bit k set = write the 512-frame segments with (segment & 3) == k (the mixed corpus interleaves generators)
+__global__ void k_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, int kind_mask, double amp) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= frames) return;
+  if (f >= frames || !((kind_mask >> ((f >> 9) & 3)) & 1)) return;
   uint32_t s = frame_states[f];
   float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512);
   for (int i = 0; i < 128; i++) {
     float4 v;
-    v.x = f32(xorshift_u(s) * 0.5); v.y = f32(xorshift_u(s) * 0.5);
-    v.z = f32(xorshift_u(s) * 0.5); v.w = f32(xorshift_u(s) * 0.5);
+    v.x = f32(xorshift_u(s) * amp); v.y = f32(xorshift_u(s) * amp);
+    v.z = f32(xorshift_u(s) * amp); v.w = f32(xorshift_u(s) * amp);
     dst[i] = v;
   }
 }
+// stationary partials with a slow amplitude modulation: the input class where binary32 arithmetic flips the most
+// decisions.  One thread per frame; the partials change from segment to segment.
+__global__ void k_generate_sines(int64_t frames, float *pcm, int kind_mask, uint32_t seed) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= frames || !((kind_mask >> ((f >> 9) & 3)) & 1)) return;
+  const uint32_t seg = (uint32_t)(f >> 9) * 2654435761u + seed;
+  const double f0 = 55.0 * exp2((double)(seg % 61u) / 12.0), f1 = f0 * (2.0 + (double)((seg >> 8) % 5u)), f2 = 3000.0 + (double)((seg >> 16) % 9000u);
+  const double w0 = 6.283185307179586 * f0 / 44100.0, w1 = 6.283185307179586 * f1 / 44100.0, w2 = 6.283185307179586 * f2 / 44100.0;
+  const double wm = 6.283185307179586 * 0.7 / 44100.0;
+  float *dst = pcm + f * 512;
+  for (int i = 0; i < 512; i++) {
+    const double t = (double)((f & 511) * 512 + i);
+    const double v = (0.45 * sin(w0 * t) + 0.12 * sin(w1 * t + 1.0) + 0.02 * sin(w2 * t + 2.0)) * (1.0 + 0.3 * sin(wm * t));
+    dst[i] = f32(v);
+  }
+}
 // one thread per 512-frame segment: p = 0.98p + 0.05u, plus 0.8u' in the second half of frames 5 mod 8
-__global__ void k_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm) {
+__global__ void k_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, int kind_mask) {
   const int64_t seg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg * 512 >= frames) return;
+  if (seg * 512 >= frames || !((kind_mask >> (seg & 3)) & 1)) return;
   uint32_t s = segment_states[seg];
   const int64_t fend = (seg + 1) * 512 < frames ? (seg + 1) * 512 : frames;
   double p = 0.0;
@@ -112,12 +129,15 @@ __global__ void k_pcm_to_int16(const float *__restrict__ in0, const float *__res
 
 }  // namespace
 
-void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, hipStream_t stream) {
-  hipLaunchKernelGGL(k_generate_white, dim3((unsigned)((frames + 63) / 64)), dim3(64), 0, stream, frame_states, frames, pcm);
+void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, int kind_mask, double amp, hipStream_t stream) {
+  hipLaunchKernelGGL(k_generate_white, dim3((unsigned)((frames + 63) / 64)), dim3(64), 0, stream, frame_states, frames, pcm, kind_mask, amp);
 }
-void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, hipStream_t stream) {
+void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, int kind_mask, hipStream_t stream) {
   const int64_t segs = (frames + 511) / 512;
-  hipLaunchKernelGGL(k_generate_pink, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, stream, segment_states, frames, pcm);
+  hipLaunchKernelGGL(k_generate_pink, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, stream, segment_states, frames, pcm, kind_mask);
+}
+void c1k_launch_generate_sines(int64_t frames, float *pcm, int kind_mask, uint32_t seed, hipStream_t stream) {
+  hipLaunchKernelGGL(k_generate_sines, dim3((unsigned)((frames + 63) / 64)), dim3(64), 0, stream, frames, pcm, kind_mask, seed);
 }
 void c1k_launch_pcm_from_int(const void *src, int bits, int channels, int64_t n, float *const *pcm, hipStream_t stream) {
   const uint8_t *s = static_cast<const uint8_t *>(src);

@@ -47,8 +47,7 @@ struct PackLds {
   uint32_t words[56];         // the unit as big-endian 32-bit groups
   uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
   double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
-  float normf[52];            // speculative path: fl32 of the same, and the guard band eps_band * norm of the BFU
-  float guard[52];
+  float2 ng[52];              // speculative path: (fl32 of the same, guard band eps_band * norm (1 + 2^-20) + 2^-22 of the BFU)
 };
 
 // One wave per sound unit.  A lane owns 8 consecutive coefficient slots (BFU-major order == bitstream
@@ -163,13 +162,14 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     const float eb = SPEC ? __shfl(h0.eps, lane >= 36 ? 2 : (lane >= 20 ? 1 : 0)) : 0.0f;
     if (lane < 52) {
       const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
-      S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
       if constexpr (SPEC) {
+        // all-long: the third field is the quantizer's range 2^(bits-1) - 1 instead of a coefficient position
+        S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)((1 << (bits_b > 0 ? bits_b - 1 : 0)) - 1) << 16);
         const float nf = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0f;
         const float g = eb * nf;
-        S.normf[lane] = nf;
-        S.guard[lane] = __builtin_fmaf(g, 9.5367431640625e-07f, g);       // * (1 + 2^-20)
+        S.ng[lane] = make_float2(nf, __builtin_fmaf(g, 9.5367431640625e-07f, g) + 2.384185791015625e-07f);
       } else {
+        S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
         S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
       }
     }
@@ -190,10 +190,49 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
       put_bits_be(S.words, 16 + 4 * n + 24 * lane, t, 24);
     }
     // mantissas
+    bool doubtful = false;
+    if constexpr (SPEC) {
+      // Branch-free: a lane's eight slots are consecutive in the bit stream, so its cursor is the position of slot 0.
+      // Two mantissas (<= 32 bits) are appended to a 64-bit accumulator that holds < 32 bits, then at most one
+      // 32-bit group is complete; it is OR-ed into the unit (a zero when none is: every lane issues the same five
+      // LDS operations, groups shared with a neighbour need the OR anyway).
+      // Quantization: |x| * norm + 0.5 in one fused operation; the reference's value of it lies within
+      // et = guard + 2^-22 a of a, so the truncation is certain when fract(a) is in (et, 1 - et).
+      const uint32_t d0 = S.desc[slot_b[0]];
+      const int pos0 = (int)((d0 >> 5) & 0x7ff) + slot_j[0] * (int)(d0 & 31);
+      int cnt = pos0 & 31, wi = pos0 >> 5;
+      uint64_t acc = 0;
+      float worst = 1.0f;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+#pragma unroll
+        for (int m = 2 * p; m < 2 * p + 2; m++) {
+          const uint32_t dsc = S.desc[slot_b[m]];
+          const float2 ng = S.ng[slot_b[m]];
+          const int bits = dsc & 31, range = (int)(dsc >> 16);
+          const float a = __builtin_fmaf(fabsf(x[m]), ng.x, 0.5f);
+          const int32_t q = (int32_t)a;                           // truncation; a >= 0
+          const float d = __builtin_amdgcn_fractf(a);
+          const float et = __builtin_fmaf(a, 2.384185791015625e-07f, ng.y);
+          worst = fminf(worst, fminf(d - et, (1.0f - et) - d));
+          const int32_t qc = q > range ? range : q;
+          const int32_t sg = __float_as_int(x[m]) >> 31;          // all ones for negative x
+          const uint32_t v = (uint32_t)((qc ^ sg) - sg) & (uint32_t)(2 * range + 1);
+          acc = (acc << bits) | v;
+          cnt += bits;
+        }
+        const bool full = cnt >= 32;
+        const uint32_t w = full ? (uint32_t)(acc >> ((cnt - 32) & 31)) : 0u;
+        atomicOr(&S.words[wi], w);
+        cnt = full ? cnt - 32 : cnt;
+        wi += full ? 1 : 0;
+      }
+      atomicOr(&S.words[wi], (uint32_t)(acc << ((32 - cnt) & 63)));   // the low cnt bits are the unwritten ones (cnt = 0: nothing)
+      doubtful = !(worst > 0.0f);
+    } else {
     uint64_t acc = 0;
     int cnt = -1, wi = 0;
     bool first = true;
-    bool doubtful = false;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const uint32_t dsc = S.desc[slot_b[m]];
@@ -205,16 +244,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
       }
       const int32_t range = (1 << (bits > 0 ? bits - 1 : 0)) - 1;
       int32_t y;
-      if constexpr (SPEC) {
-        // |x| * norm + 0.5 in one fused operation; the reference's value of it lies within et of a
-        const float a = __builtin_fmaf(fabsf(x[m]), S.normf[slot_b[m]], 0.5f);
-        const int32_t q = (int32_t)a;                           // truncation; a >= 0
-        const float d = a - (float)q;                           // exact
-        const float et = __builtin_fmaf(a, 2.384185791015625e-07f, S.guard[slot_b[m]]) + 2.384185791015625e-07f;   // + 2^-22 a + 2^-22
-        doubtful |= bits != 0 && !(d > et && d < 1.0f - et);
-        const int32_t qc = q > range ? range : q;
-        y = x[m] < 0.0f ? -qc : qc;
-      } else {
+      {
         const double xs = (double)x[m] * S.normd[slot_b[m]];
         const double v = xs + (xs >= 0 ? 0.5 : -0.5);            // round half away from zero ...
         y = (int32_t)v;                                          // ... then `| 0`: truncation; exact wrap below
@@ -233,6 +263,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
       }
     }
     if (cnt > 0) atomicOr(&S.words[wi], (uint32_t)(acc << (32 - cnt)));
+    }
     wave_sync();
     if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
     if constexpr (SPEC) {

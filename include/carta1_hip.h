@@ -161,11 +161,14 @@ int c1_dec_stream_push(c1_dec_stream *s, const uint8_t *units /* host */, int64_
 int c1_dec_stream_destroy(c1_dec_stream *s);
 
 /* ---- device-resident synthetic input for measurement ------------- */
-enum { C1_SIGNAL_WHITE = 0, C1_SIGNAL_PINK_BURSTS = 1 };
+enum { C1_SIGNAL_WHITE = 0, C1_SIGNAL_PINK_BURSTS = 1, C1_SIGNAL_MIXED = 2, C1_SIGNAL_PARTIALS = 3 };
 /* Fills pcm (DEVICE pointer, frames*512 floats) with a signal of the given statistics.  Every 512-
  * frame segment restarts xorshift32 from a seed derived from (seed, segment), so segments are
  * generated in parallel; segment 0 with seed s reproduces the first 512 frames of the generators
- * in BASELINE.md section 4 exactly (the parity subset). */
+ * in BASELINE.md section 4 exactly (the parity subset).  C1_SIGNAL_MIXED is the synthetic corpus of BASELINE configs[3]:
+ * 512-frame segments cycling white noise, pink noise with bursts, stationary partials with slow amplitude modulation
+ * and quiet white noise; C1_SIGNAL_PARTIALS is the tonal segment kind alone (parity subsets of both are checked by
+ * copying the generated PCM back to the host). */
 int c1_generate_device(c1_ctx *ctx, int signal, uint32_t seed, int64_t frames, float *pcm);
 
 /* ---- the data formats either side of the path -------------- */
