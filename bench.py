@@ -424,6 +424,13 @@ def main():
                          'decoded_pcm_rms_vs_oracle': rms, 'decoded_pcm_bit_identical_to_oracle': bool(bits),
                          'mid_stream_slice_with_halo_equals_full_run': mid_ok}
         del p3, u3, outp
+        # the frame closures of the JavaScript host: one GPU round trip per 512-sample frame (reported, not optimised)
+        try:
+            r = subprocess.run(['node', os.path.join(ROOT, 'carta1_amd', 'js', 'tools', 'latency.mjs')], capture_output=True,
+                               text=True, timeout=120)
+            ex['js_closure_latency'] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {'error': (r.stderr or r.stdout)[-300:]}
+        except Exception as e:   # noqa: BLE001
+            ex['js_closure_latency'] = {'error': str(e)}
         line['extras'] = ex
 
     if rank == 0:

@@ -56,6 +56,10 @@ SIGNATURES = {
                                    C.POINTER(EncodeOptions), C.c_void_p]),
     'c1_encode_batch': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                   C.POINTER(EncodeOptions), C.c_void_p]),
+    'c1_encode_batch_multi': (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
+                                        C.POINTER(EncodeOptions), C.c_void_p]),
+    'c1_decode_batch_multi': (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                        C.POINTER(C.c_void_p)]),
     'c1_decode_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     'c1_decode_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     'c1_enc_stream_create': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EncodeOptions), C.POINTER(C.c_void_p)]),

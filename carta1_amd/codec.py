@@ -225,6 +225,33 @@ class Context:
             C.c_void_p(coefs_ptr), C.c_void_p(eps_ptr), C.c_void_p(side_ptr)))
 
 
+def encode_multi(channels, options=None, devices=(0,)):
+    """c1_encode_batch_multi: the batch sharded over `devices` (contiguous frame ranges, one host thread and context
+    per entry, no collective).  channels: a stream from its start.  Same bytes as one device produces."""
+    opts = (options or EncoderOptions()).to_c()
+    chans = [np.ascontiguousarray(c, dtype=np.float32) for c in channels]
+    n = len(chans[0])
+    if any(len(c) != n for c in chans) or n % 512:
+        raise ValueError('channels must have equal length, a multiple of 512')
+    frames = n // 512
+    units = np.zeros((frames * len(chans), 212), dtype=np.uint8)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    capi.check(capi.load().c1_encode_batch_multi(devs, len(devices), capi.ptr_array([c.ctypes.data for c in chans]),
+                                                 len(chans), frames, 0, C.byref(opts), units.ctypes.data))
+    return units
+
+
+def decode_multi(units, channels, devices=(0,)):
+    """c1_decode_batch_multi: units of a stream from its start -> list of float32 arrays."""
+    u = np.ascontiguousarray(units, dtype=np.uint8).reshape(-1, 212)
+    frames = u.shape[0] // channels
+    outs = [np.zeros(frames * 512, dtype=np.float32) for _ in range(channels)]
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    capi.check(capi.load().c1_decode_batch_multi(devs, len(devices), u.ctypes.data, channels, frames, 0,
+                                                 capi.ptr_array([o.ctypes.data for o in outs])))
+    return outs
+
+
 class EncoderStream:
     """What one encode() closure per channel + BufferPool is in the reference: push frames, get units,
     state carried on the device between calls."""

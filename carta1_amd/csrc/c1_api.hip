@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "c1_internal.h"
@@ -1227,6 +1228,109 @@ int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fra
     HIP_TRY(hipMemcpyAsync(pcm[c], dptr[c], ch_bytes, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+// ---- one batch over several devices ------------------------------------------------------------------------------------
+namespace {
+struct ShardPool {
+  std::mutex mu;
+  std::vector<std::pair<int, c1_ctx *>> ctxs;      // entry i serves shard i when its device matches
+  c1_ctx *get(size_t shard, int device, int *rc) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (ctxs.size() <= shard) ctxs.resize(shard + 1, {-1, nullptr});
+    if (ctxs[shard].second && ctxs[shard].first != device) { c1_ctx_destroy(ctxs[shard].second); ctxs[shard] = {-1, nullptr}; }
+    if (!ctxs[shard].second) {
+      c1_ctx *c = nullptr;
+      *rc = c1_ctx_create(device, nullptr, &c);
+      if (*rc) return nullptr;
+      ctxs[shard] = {device, c};
+    }
+    *rc = C1_OK;
+    return ctxs[shard].second;
+  }
+};
+ShardPool g_shards;
+
+// contiguous ranges whose sizes differ by at most one frame
+void shard_plan(int64_t frames, int shards, std::vector<std::pair<int64_t, int64_t>> *plan) {
+  const int64_t base = frames / shards, extra = frames % shards;
+  int64_t at = 0;
+  for (int r = 0; r < shards; r++) {
+    const int64_t n = base + (r < extra ? 1 : 0);
+    plan->push_back({at, at + n});
+    at += n;
+  }
+}
+}  // namespace
+
+int c1_encode_batch_multi(const int *devices, int n_devices, const float *const *pcm, int channels, int64_t frames,
+                          int halo_frames, const c1_encode_options *opts, uint8_t *units) {
+  int rc = check_channels(channels);
+  if (rc) return rc;
+  if (!devices || n_devices < 1 || n_devices > 64) return fail(C1_ERR_ARG, "devices: 1..64 entries");
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
+  if (frames == 0) return C1_OK;
+  if (!pcm || !units || !opts) return fail(C1_ERR_ARG, "NULL argument");
+  for (int c = 0; c < channels; c++) if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+  const int shards = (int)std::min<int64_t>(n_devices, frames);
+  std::vector<std::pair<int64_t, int64_t>> plan;
+  shard_plan(frames, shards, &plan);
+  std::vector<c1_ctx *> ctxs(shards);
+  for (int s = 0; s < shards; s++) {
+    ctxs[s] = g_shards.get((size_t)s, devices[s], &rc);
+    if (rc) return rc;                               // c1_last_error() of this thread holds the reason
+  }
+  std::vector<int> rcs(shards, C1_OK);
+  std::vector<std::string> errs(shards);
+  std::vector<std::thread> threads;
+  for (int s = 0; s < shards; s++)
+    threads.emplace_back([&, s] {
+      const int64_t a = plan[s].first, b = plan[s].second;
+      const int h = (int)std::min<int64_t>(2, a + halo_frames);        // frames of real PCM directly in front of the range
+      const float *ptrs[C1_MAX_CHANNELS] = {nullptr, nullptr};
+      for (int c = 0; c < channels; c++) ptrs[c] = pcm[c] + a * 512;
+      rcs[s] = c1_encode_batch(ctxs[s], ptrs, channels, b - a, h, opts, units + (size_t)a * channels * C1_UNIT_BYTES);
+      if (rcs[s]) errs[s] = c1_last_error();
+    });
+  for (auto &t : threads) t.join();
+  for (int s = 0; s < shards; s++)
+    if (rcs[s]) return fail(rcs[s], "shard %d on device %d: %s", s, devices[s], errs[s].c_str());
+  return C1_OK;
+}
+
+int c1_decode_batch_multi(const int *devices, int n_devices, const uint8_t *units, int channels, int64_t frames,
+                          int halo_units, float *const *pcm) {
+  int rc = check_channels(channels);
+  if (rc) return rc;
+  if (!devices || n_devices < 1 || n_devices > 64) return fail(C1_ERR_ARG, "devices: 1..64 entries");
+  if (frames < 0 || halo_units < 0 || halo_units > 1) return fail(C1_ERR_ARG, "bad frames / halo_units");
+  if (frames == 0) return C1_OK;
+  if (!pcm || !units) return fail(C1_ERR_ARG, "NULL argument");
+  for (int c = 0; c < channels; c++) if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+  const int shards = (int)std::min<int64_t>(n_devices, frames);
+  std::vector<std::pair<int64_t, int64_t>> plan;
+  shard_plan(frames, shards, &plan);
+  std::vector<c1_ctx *> ctxs(shards);
+  for (int s = 0; s < shards; s++) {
+    ctxs[s] = g_shards.get((size_t)s, devices[s], &rc);
+    if (rc) return rc;
+  }
+  std::vector<int> rcs(shards, C1_OK);
+  std::vector<std::string> errs(shards);
+  std::vector<std::thread> threads;
+  for (int s = 0; s < shards; s++)
+    threads.emplace_back([&, s] {
+      const int64_t a = plan[s].first, b = plan[s].second;
+      const int h = a > 0 ? 1 : halo_units;
+      float *ptrs[C1_MAX_CHANNELS] = {nullptr, nullptr};
+      for (int c = 0; c < channels; c++) ptrs[c] = pcm[c] + a * 512;
+      rcs[s] = c1_decode_batch(ctxs[s], units + (size_t)a * channels * C1_UNIT_BYTES, channels, b - a, h, ptrs);
+      if (rcs[s]) errs[s] = c1_last_error();
+    });
+  for (auto &t : threads) t.join();
+  for (int s = 0; s < shards; s++)
+    if (rcs[s]) return fail(rcs[s], "shard %d on device %d: %s", s, devices[s], errs[s].c_str());
   return C1_OK;
 }
 

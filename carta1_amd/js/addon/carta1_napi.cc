@@ -322,6 +322,7 @@ struct AsyncJob {
   napi_ref keep[4] = {nullptr, nullptr, nullptr, nullptr};
   int nkeep = 0;
   c1_ctx *ctx = nullptr;
+  std::vector<int> devices;          // non-empty: the *_multi entry points (one context per entry, owned by the library)
   bool encode = true;
   int channels = 1, halo = 0;
   int64_t frames = 0;
@@ -336,8 +337,12 @@ struct AsyncJob {
 };
 void AsyncExecute(napi_env, void *data) {
   AsyncJob *j = static_cast<AsyncJob *>(data);
-  j->rc = j->encode ? c1_encode_batch(j->ctx, j->in, j->channels, j->frames, j->halo, &j->opts, j->units_out)
-                    : c1_decode_batch(j->ctx, j->units_in, j->channels, j->frames, j->halo, j->outp);
+  if (!j->devices.empty())
+    j->rc = j->encode ? c1_encode_batch_multi(j->devices.data(), (int)j->devices.size(), j->in, j->channels, j->frames, j->halo, &j->opts, j->units_out)
+                      : c1_decode_batch_multi(j->devices.data(), (int)j->devices.size(), j->units_in, j->channels, j->frames, j->halo, j->outp);
+  else
+    j->rc = j->encode ? c1_encode_batch(j->ctx, j->in, j->channels, j->frames, j->halo, &j->opts, j->units_out)
+                      : c1_decode_batch(j->ctx, j->units_in, j->channels, j->frames, j->halo, j->outp);
   if (j->rc) j->err = c1_last_error();   // thread-local: read it on the worker thread
 }
 void AsyncComplete(napi_env env, napi_status, void *data) {
@@ -369,6 +374,21 @@ napi_value start_job(napi_env env, AsyncJob *j, const char *name) {
   }
   return promise;
 }
+// argv[0]: a context, or (multi) an array of device indices
+bool get_ctx_or_devices(napi_env env, napi_value v, AsyncJob *j) {
+  bool is_array = false;
+  if (napi_is_array(env, v, &is_array) != napi_ok) return false;
+  if (!is_array) return get_external(env, v, &j->ctx);
+  uint32_t n = 0;
+  if (napi_get_array_length(env, v, &n) != napi_ok || n < 1 || n > 64) return false;
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value e;
+    int32_t d = 0;
+    if (napi_get_element(env, v, i, &e) != napi_ok || napi_get_value_int32(env, e, &d) != napi_ok) return false;
+    j->devices.push_back(d);
+  }
+  return true;
+}
 napi_value EncodeBatchAsync(napi_env env, napi_callback_info info) {
   napi_value argv[4];
   if (!get_args(env, info, 4, argv)) return nullptr;
@@ -376,7 +396,7 @@ napi_value EncodeBatchAsync(napi_env env, napi_callback_info info) {
   std::vector<float *> ch;
   size_t samples = 0;
   int32_t halo = 0;
-  if (!get_external(env, argv[0], &j->ctx) || !get_channels(env, argv[1], &ch, &samples) ||
+  if (!get_ctx_or_devices(env, argv[0], j) || !get_channels(env, argv[1], &ch, &samples) ||
       napi_get_value_int32(env, argv[2], &halo) != napi_ok || !get_options(env, argv[3], &j->opts) ||
       samples % 512 || (int64_t)(samples / 512) < halo) {
     delete j;
@@ -408,7 +428,7 @@ napi_value DecodeBatchAsync(napi_env env, napi_callback_info info) {
   void *d;
   size_t n;
   int32_t channels = 1, halo = 0;
-  if (!get_external(env, argv[0], &j->ctx) || !get_typed(env, argv[1], napi_uint8_array, &d, &n) ||
+  if (!get_ctx_or_devices(env, argv[0], j) || !get_typed(env, argv[1], napi_uint8_array, &d, &n) ||
       napi_get_value_int32(env, argv[2], &channels) != napi_ok || napi_get_value_int32(env, argv[3], &halo) != napi_ok ||
       channels < 1 || channels > 2 || n % ((size_t)channels * C1_UNIT_BYTES) ||
       (int64_t)(n / ((size_t)channels * C1_UNIT_BYTES)) < halo) {

@@ -29,20 +29,23 @@ export async function encodeAeaPcm(channels, options = {}) {
       channels.some((channel) => !(channel instanceof Float32Array))) {
     throw new TypeError('ATRAC1 encoding requires one or two Float32 channels')
   }
-  const { title = 'encoded by carta1', ...encoderValues } = options
+  // options.devices (not in the reference): device indices to shard the frame batch over, e.g. [0, 1, 2, 3]; contiguous
+  // frame ranges, one context and host thread per entry, no collective -- same bytes as one device
+  const { title = 'encoded by carta1', devices, ...encoderValues } = options
   const encoderOptions = new EncoderOptions(encoderValues)
   const { frames, padded } = padChannels(channels)
   const unitCount = frames * channels.length
   const image = new Uint8Array(AEA_HEADER_SIZE + unitCount * SOUND_UNIT_SIZE)
   image.set(AeaFile.createHeader(title, unitCount, channels.length), 0) // frameCount counts units: processor.js:320-325
   if (frames > 0) {
-    const units = await native().encodeBatchAsync(context(), padded, 0, encoderOptions.toNative())
+    const where = Array.isArray(devices) && devices.length ? devices : context()
+    const units = await native().encodeBatchAsync(where, padded, 0, encoderOptions.toNative())
     image.set(units, AEA_HEADER_SIZE)
   }
   return image
 }
 
-export async function decodeAeaPcm(input) {
+export async function decodeAeaPcm(input, options = {}) {
   let bytes
   if (input instanceof Uint8Array) bytes = input
   else if (input instanceof ArrayBuffer) bytes = new Uint8Array(input)
@@ -60,7 +63,8 @@ export async function decodeAeaPcm(input) {
     body[units.length] = 0xac
   }
   if (body.length === 0) return nch === 1 ? [new Float32Array(0)] : [new Float32Array(0), new Float32Array(0)]
-  return native().decodeBatchAsync(context(), body, nch, 0)
+  const where = Array.isArray(options.devices) && options.devices.length ? options.devices : context()
+  return native().decodeBatchAsync(where, body, nch, 0)
 }
 
 // WAV body (interleaved little-endian integer PCM: Int16Array, or a Uint8Array with bits = 16, 24 or 32) -> AEA image.

@@ -161,6 +161,16 @@ async function main() {
       const same = (x, y) => Buffer.from(x.buffer, x.byteOffset, x.byteLength).equals(Buffer.from(y.buffer, y.byteOffset, y.byteLength))
       ok(same(pa[0], sa[0]) && same(pa[1], sa[1]) && same(pb[0], sb[0]) && same(pb[1], sb[1]), 'Promise.all of decodes on one context == sequential results')
     }
+    // the batch sharded over device contexts (here the same device three times): same bytes, same PCM
+    {
+      const src = [pinkT(61, 500 * 512), white(62, 500 * 512)]
+      const one = await c1.encodeAeaPcm(src, {})
+      const three = await c1.encodeAeaPcm(src, { devices: [0, 0, 0] })
+      ok(hex(one) === hex(three), 'encodeAeaPcm sharded over devices [0,0,0] == one device')
+      const p1 = await c1.decodeAeaPcm(one), p3 = await c1.decodeAeaPcm(one, { devices: [0, 0, 0] })
+      const same = (x, y) => Buffer.from(x.buffer, x.byteOffset, x.byteLength).equals(Buffer.from(y.buffer, y.byteOffset, y.byteLength))
+      ok(same(p1[0], p3[0]) && same(p1[1], p3[1]), 'decodeAeaPcm sharded over devices [0,0,0] == one device')
+    }
     // a stereo image that ends on a lone left unit: both decode entry points pair it with the dummy unit
     {
       const img = await c1.encodeAeaPcm([white(51, 3 * 512), white(52, 3 * 512)], {})

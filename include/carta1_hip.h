@@ -131,6 +131,17 @@ int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t
 int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
                     int halo_frames, const c1_encode_options *opts, uint8_t *units);
 
+/* The same batch sharded over several devices of this host (the hot loop of processor.js:119-136 has no
+ * dependency between frames beyond a bounded PCM history): contiguous frame ranges, one per entry of `devices`, each
+ * encoded by its own host thread on a context of that device from its 2 frames of real PCM history; no collective, the
+ * ranges land in `units` by frame index.  A device may be listed more than once (each entry gets its own context).
+ * Contexts are created on first use and kept for the life of the process.  Bit-identical to c1_encode_batch. */
+int c1_encode_batch_multi(const int *devices, int n_devices, const float *const *pcm, int channels, int64_t frames,
+                          int halo_frames, const c1_encode_options *opts, uint8_t *units);
+/* decode twin: every range starts from the unit(s) of the frame before it */
+int c1_decode_batch_multi(const int *devices, int n_devices, const uint8_t *units, int channels, int64_t frames,
+                          int halo_units, float *const *pcm);
+
 /* Page-locked host memory for the *_batch calls.  When the PCM buffers handed to c1_encode_batch /
  * c1_decode_batch lie in memory from c1_host_alloc (or otherwise registered with HIP), the call streams the
  * batch in chunks: upload of chunk i+1, kernels of chunk i and download of chunk i-1 overlap, and the PCIe link

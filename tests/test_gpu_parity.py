@@ -558,3 +558,21 @@ def test_sharded_encode_and_decode_equal_one_device(ctx):
     pcm_got = c1.decode_sharded(want, 2, devices=(0, 0, 0, 0))
     for c in range(2):
         assert np.array_equal(pcm_got[c].view(np.uint32), pcm_want[c].view(np.uint32))
+
+
+def test_multi_device_entry_points_equal_one_device(ctx):
+    """c1_encode_batch_multi / c1_decode_batch_multi with the same device listed three times (the box has one GPU):
+    contiguous shards from their halo, bit-identical to the single-context calls, for detection and fixed modes"""
+    import carta1_amd as c1
+    n = 1000 * 512
+    chans = [O.gen_pinkT(3, n), O.gen_white(2, n)]
+    for opts in (c1.EncoderOptions(), c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}), c1.EncoderOptions({'fixedBlockModes': [2, 0, 3]})):
+        one = ctx.encode(chans, opts)
+        multi = c1.encode_multi(chans, opts, devices=(0, 0, 0))
+        assert np.array_equal(one, multi)
+        a = ctx.decode(one, 2)
+        b = c1.decode_multi(one, 2, devices=(0, 0, 0))
+        for c in range(2):
+            assert np.array_equal(a[c].view(np.uint32), b[c].view(np.uint32))
+    mono = c1.encode_multi([chans[0][:5 * 512]], c1.EncoderOptions(), devices=(0, 0, 0, 0, 0, 0, 0, 0))   # more shards than frames
+    assert np.array_equal(mono, ctx.encode([chans[0][:5 * 512]], c1.EncoderOptions()))
