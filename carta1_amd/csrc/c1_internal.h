@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/carta1_hip.h"
 
@@ -107,17 +108,16 @@ struct C1DecodeLaunch {
   int run_frames;        // consecutive units of one channel a wave decodes (set by the launcher)
 };
 
-// Run length of the frame-walking kernels.  Every wave of a launch does the same amount of work, so a grid of W waves
-// on a machine with S wave slots takes ceil(W / S) rounds: 16 384 runs of 64 frames on 5 120 slots are 4 rounds, the
-// last one a fifth full.  The launchers therefore size the runs so that one launch fills the slots once (long runs
-// also amortise the warm-up frame), and never below kMinRun frames, where the warm-up would cost too much.
-constexpr int kMinRun = 16;
+// Run length of the frame-walking kernels: consecutive frames of one channel a wave walks, carrying the filter state
+// (one extra warm-up frame per run).  Measured on MI355X (1 M stereo frames, A/B in one session): 64-frame runs beat
+// runs sized to fill the wave slots exactly once (205 frames: every wave then finishes at the same moment, and the
+// dispatcher has nothing left to balance) by 5 % (speculative analysis) to 8 % (decode); 32 and 128 are within noise
+// of 64.  C1_RUN_FRAMES overrides it for experiments.
+constexpr int kRunDefault = 64;
 inline int c1k_pick_run(int64_t frames, int channels, int slots) {
-  const int64_t runs_per_channel = slots / channels > 0 ? slots / channels : 1;
-  int64_t run = (frames + runs_per_channel - 1) / runs_per_channel;
-  if (run < kMinRun) run = kMinRun;
-  if (run > (1 << 20)) run = 1 << 20;
-  return (int)run;
+  static const int forced = getenv("C1_RUN_FRAMES") ? atoi(getenv("C1_RUN_FRAMES")) : 0;
+  (void)frames; (void)channels; (void)slots;
+  return forced > 0 ? forced : kRunDefault;
 }
 // wave slots of the current device for a 64-thread kernel (occupancy x compute units), cached by the caller
 template <class Kernel>

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
   __shared__ PackLds lds[kPackWaves];
   __shared__ typename std::conditional<SPEC, float, double>::type norm_s[64 * 16];   // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
   TablesPtr T = C1_TABLES(L.tables);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is uniform across the wave; telling the compiler so moves the per-unit address arithmetic (unit
+  // index, record and coefficient pointers, this wave's LDS block) from the vector to the scalar unit
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   PackLds &S = lds[wave];
   for (int i = threadIdx.x; i < 64 * 16; i += C1_WAVE * kPackWaves) {
     if constexpr (SPEC) norm_s[i] = T->norm32[i]; else norm_s[i] = T->norm[i];

@@ -444,8 +444,8 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       // so it is certain when both ends (widened by the rounding of this very subtraction / addition) agree
       const float lo = fmaxf((mx - e) * 0.99999976f, 0.0f), hi = (mx + e) * 1.00000024f;
       const int s_lo = scale_factor_index_fast(lo, T->sf_m1, T->sf_m2), s_hi = scale_factor_index_fast(hi, T->sf_m1, T->sf_m2);
-      const int sfi = scale_factor_index_fast(mx, T->sf_m1, T->sf_m2);
-      if (SFL.store) S.sfi[SFL.b] = (uint8_t)sfi;
+      // lo <= mx <= hi and the index is monotone: when both ends agree, that is the index of mx too
+      if (SFL.store) S.sfi[SFL.b] = (uint8_t)s_lo;
       unstable = lane < 60 && !(s_lo == s_hi && e < __builtin_huge_valf());
     }
     const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;
