@@ -146,8 +146,11 @@ void build_spec_tables(const c1_tables &t, C1DevTables *d) {
     if (b == 2) { d->spec_cw[b] = round_up_f32(gb * (5 * kSpecGH + kSpecGQ)); d->spec_cl[b] = 0.0f; }
     else { d->spec_cw[b] = round_up_f32(gb * kSpecGH * kSpecGQ); d->spec_cl[b] = round_up_f32(gb * (7 * kSpecGH + kSpecGQ)); }
     d->spec_cz_short[b] = round_up_f32(u * ka16 * std::sqrt(s64 * 16));
+    const double gs = u * s64 * std::sqrt(2.0 * 16);
+    if (b == 2) { d->spec_cw_short[b] = round_up_f32(gs * (5 * kSpecGH + kSpecGQ)); d->spec_cl_short[b] = 0.0f; }
+    else { d->spec_cw_short[b] = round_up_f32(gs * kSpecGH * kSpecGQ); d->spec_cl_short[b] = round_up_f32(gs * (7 * kSpecGH + kSpecGQ)); }
   }
-  d->spec_cz[3] = d->spec_cw[3] = d->spec_cl[3] = d->spec_cz_short[3] = 0.0f;
+  d->spec_cz[3] = d->spec_cw[3] = d->spec_cl[3] = d->spec_cz_short[3] = d->spec_cw_short[3] = d->spec_cl_short[3] = 0.0f;
   d->spec_eabs = (float)std::ldexp(1.0, -70);
   d->spec_ok = ok ? 1 : 0;
 }
@@ -568,7 +571,9 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   // half of the workspace.  Everything is ordered after the caller's stream and joined back into it.
   const bool all_long_modes = !detect && opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 &&
                               opts->fixed_block_modes[2] == 0 && !getenv("C1_NO_FAST_LONG");
-  bool speculate = all_long_modes && !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;
+  const bool all_short_modes = !detect && opts->fixed_block_modes[0] != 0 && opts->fixed_block_modes[1] != 0 &&
+                               opts->fixed_block_modes[2] != 0;
+  bool speculate = (all_long_modes || all_short_modes) && !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;
   if (speculate && ctx->spec_mode == 1) {
     // adaptive: look at what the previous speculative call had to redo (its kernels have normally finished by now).
     // Signals whose spectrum is far from flat (tones) fail the guard band for most units; then the speculative pass
@@ -619,17 +624,17 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       L.redo_count = ctx->d_redo[p];
       L.redo_list = ctx->d_redo[p] + 4;
       HIP_TRY(hipMemsetAsync(L.redo_count, 0, sizeof(uint32_t), sA));
-      { ScopedTiming t(ctx, K_ANALYSIS, sA); c1k_launch_analysis_spec(L, sA); }
+      { ScopedTiming t(ctx, K_ANALYSIS, sA); c1k_launch_analysis_spec(L, all_short_modes, sA); }
       { ScopedTiming t(ctx, K_ALLOCATE, sA); c1k_launch_allocate(L, sA); }
-      { ScopedTiming t(ctx, K_PACK, sA); c1k_launch_pack_spec(L, sA); }
+      { ScopedTiming t(ctx, K_PACK, sA); c1k_launch_pack_spec(L, all_long_modes, sA); }
       {
         ScopedTiming t(ctx, K_REDO, sA);
         C1EncodeLaunch R = L;
         R.unit_list = L.redo_list;
         R.unit_count = L.redo_count;
-        c1k_launch_analysis_long(R, sA);
+        if (all_long_modes) c1k_launch_analysis_long(R, sA); else c1k_launch_analysis(R, false, sA);
         c1k_launch_allocate(R, sA);
-        c1k_launch_pack(R, true, sA);
+        c1k_launch_pack(R, all_long_modes, sA);
         c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), L.redo_count, sA);
       }
       continue;
@@ -959,8 +964,10 @@ int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, in
   if ((rc = check_channels(channels))) return rc;
   if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
   if (!pcm || !opts || !coefs || !eps || !side) return fail(C1_ERR_ARG, "NULL argument");
-  if (opts->fixed_block_modes[0] != 0 || opts->fixed_block_modes[1] != 0 || opts->fixed_block_modes[2] != 0)
-    return fail(C1_ERR_ARG, "the speculative analysis covers fixed block modes [0,0,0] only");
+  const bool sp_long = opts->fixed_block_modes[0] == 0 && opts->fixed_block_modes[1] == 0 && opts->fixed_block_modes[2] == 0;
+  const bool sp_short = opts->fixed_block_modes[0] > 0 && opts->fixed_block_modes[1] > 0 && opts->fixed_block_modes[2] > 0;
+  if (!sp_long && !sp_short)
+    return fail(C1_ERR_ARG, "the speculative analysis covers fixed block modes with all bands long or all bands short");
   if (!ctx->spec_tables_ok) return fail(C1_ERR_STATE, "the installed tables fail the checks the error bound relies on");
   for (int c = 0; c < channels; c++)
     if (!pcm[c] || ((uintptr_t)pcm[c] & 15)) return fail(C1_ERR_ARG, "pcm[%d] must be a 16-byte aligned device pointer", c);
@@ -972,7 +979,7 @@ int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, in
   L.channels = channels; L.frames = frames; L.halo_frames = halo_frames;
   L.tables = ctx->d_tables; L.opts = ctx->d_opts;
   L.coefs = coefs; L.eps = eps; L.side = side;
-  c1k_launch_analysis_spec(L, ctx->stream);
+  c1k_launch_analysis_spec(L, sp_short, ctx->stream);
   HIP_TRY(hipGetLastError());
   return C1_OK;
 }

@@ -45,7 +45,7 @@ struct C1DevTables {
   float norm32[64 * 16];     // fl32(norm)
   // error-bound coefficients per band (rounded up): eps_b = cz*Z_b + cw*W + cl*L + eabs
   float spec_cz[4], spec_cw[4], spec_cl[4];
-  float spec_cz_short[4];    // cz when the band is coded with short blocks
+  float spec_cz_short[4], spec_cw_short[4], spec_cl_short[4];   // the same for a band coded with short blocks (16-point transforms)
   float spec_eabs;
   int32_t spec_ok;           // 0: the installed tables fail the structural checks the bound relies on -> exact path only
 };
@@ -131,7 +131,8 @@ inline int c1k_wave_slots(Kernel kernel) {
 // launchers (one per c1_k_*.hip file); all asynchronous on `stream`
 void c1k_launch_analysis(const C1EncodeLaunch &L, bool detect, hipStream_t stream);
 void c1k_launch_analysis_long(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0]
-void c1k_launch_analysis_spec(const C1EncodeLaunch &L, hipStream_t stream);   // fixed modes [0,0,0], binary32 + error bound
+// binary32 + error bound: fixed modes [0,0,0] (all_short = false) or all three bands short (true)
+void c1k_launch_analysis_spec(const C1EncodeLaunch &L, bool all_short, hipStream_t stream);
 // transient detection: features (runs) -> decisions (per unit) -> MDCT from the stored bands (per unit).
 // bands_ws: (units + channels) * 512 floats, feat_ws: (units + channels) * kFeatureWsDoubles doubles, modes_ws: units bytes
 constexpr int kFeatureWsDoubles = 20;
@@ -140,7 +141,7 @@ void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws
                        hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
-void c1k_launch_pack_spec(const C1EncodeLaunch &L, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
+void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
 void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
 // kind_mask: bit k = fill the 512-frame segments with (segment & 3) == k (15 = all)

@@ -263,7 +263,8 @@ void c1k_launch_analysis(const C1EncodeLaunch &L0, bool detect, hipStream_t stre
   C1EncodeLaunch L = L0;
   L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
   const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
-  const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
+  const int64_t blocks = L.unit_list ? std::min<int64_t>(L.frames * L.channels, 256 * 12) : runs * L.channels;   // list mode: bounded grid
+  const dim3 grid((unsigned)blocks), block(C1_WAVE);
   (void)detect;
   hipLaunchKernelGGL((k_analysis_fast<false>), grid, block, 0, stream, L);
 }

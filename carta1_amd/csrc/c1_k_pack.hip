@@ -287,7 +287,8 @@ void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream)
   if (all_long) hipLaunchKernelGGL((k_pack<true, false>), grid, block, 0, stream, L);
   else hipLaunchKernelGGL((k_pack<false, false>), grid, block, 0, stream, L);
 }
-void c1k_launch_pack_spec(const C1EncodeLaunch &L, hipStream_t stream) {
+void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream) {
   const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
-  hipLaunchKernelGGL((k_pack<true, true>), grid, block, 0, stream, L);
+  if (all_long) hipLaunchKernelGGL((k_pack<true, true>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_pack<false, true>), grid, block, 0, stream, L);
 }

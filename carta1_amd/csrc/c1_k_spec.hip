@@ -27,9 +27,12 @@ namespace {
 //                         outputs then start a 16-byte group)  ->  FFT points z (320 float2)
 // The zero padding of the long-block MDCT inputs is never materialised: the pre-twiddle knows which of its operands
 // fall into it (a lane-constant predicate) and takes 0 instead of reading.
-//   R2 = mem[840, 1352)   stage-2 work buffer (302)  ->  in0 | in1 (256 each)  ->  coefficients (512)
+//   R2 = mem[840, 1416)   stage-2 work buffer (302)  ->  in0 | in1 (256 each)  ->  coefficients (512)
+// With short blocks (SHORT) the MDCT inputs are staged per band as E[s] = W[s & 31] x[s] behind the previous frame's
+// 32 overlap values, and H[s] = x[s] W[31 - (s & 31)]: block q of a band is E[32 (q-1) ..) | H[32 q ..) (encoder.js:269-307).
+//   band 2: E at mem[0, 288), H at mem[288, 544);   band 0: E at R2 + 0 (160), H at R2 + 160 (128);   band 1: R2 + 288, R2 + 448
 constexpr int kR2 = 840;
-constexpr int kMemFloats = kR2 + 512;
+constexpr int kMemFloats = kR2 + 576;
 constexpr int kIn2 = 1;             // in2[i] = mem[kIn2 + i]
 struct alignas(16) SpecLds {
   alignas(16) float mem[kMemFloats];
@@ -40,6 +43,7 @@ struct alignas(16) SpecLds {
   alignas(4) uint8_t sfi[64];
 };
 static_assert(sizeof(SpecLds) <= 6656, "speculative analysis: 24 waves per CU");
+constexpr int kE2 = 0, kH2 = 288, kE0 = kR2, kH0 = kR2 + 160, kE1 = kR2 + 288, kH1 = kR2 + 448;
 
 __device__ __forceinline__ int w1_phys(int v) { return 12 * (v >> 3) + (v & 7); }
 
@@ -181,6 +185,9 @@ __device__ __forceinline__ void radix4_round(v2f (&x)[4], v2f wa, v2f wb, v2f wa
   x[3] = pk_fma(t3.yx, PNM, t1);                         // t1 + i t3
 }
 
+// SHORT = false: fixed block modes [0,0,0].  SHORT = true: all three bands coded with short blocks (any non-zero fixed
+// modes, e.g. [2,2,3]): sixteen 64-sample MDCTs = 16-point transforms per frame, rounds A and B only.
+template <bool SHORT>
 __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) {
   __shared__ SpecLds S;
   const int lane0 = threadIdx.x;
@@ -196,7 +203,15 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
   for (int i = lane; i < 72; i += 64) S.pre2[i] = 0.0f;
   if (lane < 16) reinterpret_cast<uint32_t *>(S.sfi)[lane] = 0u;
   const SpecBase B0 = spec_base(lane0);
-  const SfLong SFL0 = sf_long_geometry(lane0);
+  const SfLong SFL0 = SHORT ? sf_geometry(lane0, 2, 2, 3) : sf_long_geometry(lane0);
+  if (SHORT && lane == 0) S.sfi[52] = (uint8_t)((L.opts->modes[0] & 3) | ((L.opts->modes[1] & 3) << 2) | ((L.opts->modes[2] & 3) << 4));
+  // short blocks: lane = (band, block, r) with four points of one 16-point transform
+  const int s_band = lane0 < 16 ? 0 : (lane0 < 32 ? 1 : 2);
+  const int s_g = lane0 - (s_band == 0 ? 0 : (s_band == 1 ? 16 : 32));
+  const int s_blk = s_g >> 2, s_r2 = 2 * bitrev(s_g & 3, 2);
+  const int s_eb0 = (s_band == 0 ? kE0 : (s_band == 1 ? kE1 : kE2)) + 32 * s_blk;
+  const int s_hb0 = (s_band == 0 ? kH0 : (s_band == 1 ? kH1 : kH2)) + 32 * s_blk;
+  const int s_c0 = (s_band == 0 ? 0 : (s_band == 1 ? 128 : 256)) + 32 * s_blk + 2 * (s_g & 3);   // coefficient 2 i of the first final point
   const TablesRsrc RT = tables_rsrc(L.tables);
   float p_prev = 0.0f, q_prev = 0.0f;        // PCM / stage-1-low energies of the previous frame
   __syncthreads();
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       Q = wave_sum(q);
       // band 2 = the high band behind its 39-sample delay (encoder.js:84-90): what the previous frame left (overlap,
       // 39 samples), then this frame's outputs; the last 32 samples of the band are windowed (encoder.js:309-316)
+      if constexpr (!SHORT) {
       if (emit) for (int i = lane; i < 71; i += 64) mem[kIn2 + 112 + i] = S.pre2[i];
       if (lane <= 45) {                                     // positions 39 + 4 lane .. + 3 < 224: plain samples, one 16-byte group
         if (emit) *reinterpret_cast<float4 *>(&mem[kIn2 + 183 + 4 * lane]) = make_float4(hi[0], hi[1], hi[2], hi[3]);
@@ -281,6 +297,28 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
             const int k = pos - 224;
             S.pre2[k] = S.win[k] * x;
             if (emit) mem[kIn2 + 144 + pos] = x * S.win[31 - k];
+          } else S.pre2[32 + pos - 256] = x;
+        }
+      }
+      } else {
+        // short blocks: every sample enters twice, E = W[pos & 31] x (second half of block q-1's... first half of the
+        // NEXT block's input) and H = x W[31 - (pos & 31)]; the frame starts with the overlap and the 39 delayed samples
+        if (emit) {
+          if (lane < 32) mem[kE2 + lane] = S.pre2[lane];
+          if (lane < 39) {
+            const float x = S.pre2[32 + lane];
+            mem[kE2 + 32 + lane] = S.win[lane & 31] * x;
+            mem[kH2 + lane] = x * S.win[31 - (lane & 31)];
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const int pos = 39 + 4 * lane + d;
+          const float x = hi[d];
+          if (pos < 256) {
+            const float e = S.win[pos & 31] * x;
+            if (emit) { mem[kE2 + 32 + pos] = e; mem[kH2 + pos] = x * S.win[31 - (pos & 31)]; }
+            if (pos >= 224) S.pre2[pos - 224] = e;
           } else S.pre2[32 + pos - 256] = x;
         }
       }
@@ -300,6 +338,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
         qmf_core_f32<2>(W, T, lo, hi);
       } else { for (int d = 0; d < 2; d++) { lo[d] = mem[lane + d]; hi[d] = 1.0f; } }
       if (lane < 46) S.d2[lane] = mem[kR2 + 256 + lane];
+      if constexpr (!SHORT) {
       if (lane < 48) {
         if (emit) {
           *reinterpret_cast<float2 *>(&mem[kR2 + 80 + 2 * lane]) = make_float2(lo[0], lo[1]);
@@ -319,12 +358,31 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
         ov0a = wl0 * lo[0]; ov0b = wl1 * lo[1];
         ov1a = wl0 * hi[0]; ov1b = wl1 * hi[1];
       }
+      } else {
+        const int k = (2 * lane) & 31;
+        const float wl0 = S.win[k], wl1 = S.win[k + 1], wh0 = S.win[31 - k], wh1 = S.win[30 - k];
+        const float e00 = wl0 * lo[0], e01 = wl1 * lo[1], e10 = wl0 * hi[0], e11 = wl1 * hi[1];
+        if (emit) {
+          if (lane >= 48) {                                 // the overlap the previous frame left: E[0, 32)
+            *reinterpret_cast<float2 *>(&mem[kE0 + 2 * (lane - 48)]) = make_float2(ov0a, ov0b);
+            *reinterpret_cast<float2 *>(&mem[kE1 + 2 * (lane - 48)]) = make_float2(ov1a, ov1b);
+          }
+          *reinterpret_cast<float2 *>(&mem[kE0 + 32 + 2 * lane]) = make_float2(e00, e01);
+          *reinterpret_cast<float2 *>(&mem[kE1 + 32 + 2 * lane]) = make_float2(e10, e11);
+          *reinterpret_cast<float2 *>(&mem[kH0 + 2 * lane]) = make_float2(lo[0] * wh0, lo[1] * wh1);
+          *reinterpret_cast<float2 *>(&mem[kH1 + 2 * lane]) = make_float2(hi[0] * wh0, hi[1] * wh1);
+        }
+        if (lane >= 48) { ov0a = e00; ov0b = e01; ov1a = e10; ov1b = e11; }
+      }
     }
     const float W = __builtin_amdgcn_sqrtf(P + p_prev), Lw = __builtin_amdgcn_sqrtf(Q + q_prev);
     p_prev = P; q_prev = Q;
     __syncthreads();
     if (!emit) continue;
 
+    v2f x[4];
+    float zrow;
+    if constexpr (!SHORT) {
     // ---------------- long-block MDCT in binary32 ----------------
     // position 4g + j of the lane holds point k_j = r + q * bitrev2(j): j = 1 -> 2q, j = 2 -> q, j = 3 -> 3q
     // (the base values pass through an opaque asm once per frame: otherwise every address derived from them is
@@ -333,8 +391,6 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     asm volatile("" : "+v"(B.ia0), "+v"(B.ic0), "+v"(B.q2), "+v"(B.ib), "+v"(B.id), "+v"(B.pt0));
     asm volatile("" : "+v"(B.za), "+v"(B.zb), "+v"(B.zc), "+v"(B.zd), "+v"(B.g));
     asm volatile("" : "+v"(B.e0), "+v"(B.e1), "+v"(B.po0));
-    v2f x[4];
-    float zrow;
     {
       const int qb = 4 * B.q2;                               // bytes between the pre-twiddle pairs of points q apart
       const v2f t0 = table_f2(RT, B.pt0), t1 = table_f2(RT, B.pt0 + 2 * qb);
@@ -400,7 +456,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       const v2f e0 = x[0], e2 = x[2];
       x[0] = e0 + y1; x[1] = e0 - y1; x[2] = e2 + y3; x[3] = e2 - y3;
     }
-    float *coef = mem + kR2;
+    float *coefw = mem + kR2;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const v2f t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
@@ -409,11 +465,80 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       // mdct.js:110-119: out[2 i] = -(re c + im s), out[n2 - 1 - 2 i] = im c - re s
       const v2f u = x[j].yx * (t.yy * PMN);                  // (im s, -(re s))
       const v2f o = pk_fma(x[j], t.xx, u);
-      coef[B.band0 ? e0 : e1] = -o.x;
-      coef[B.band0 ? e1 : e0] = o.y;
+      coefw[B.band0 ? e0 : e1] = -o.x;
+      coefw[B.band0 ? e1 : e0] = o.y;
     }
     __syncthreads();
 
+    }
+    float *coef = mem + kR2;
+    if constexpr (SHORT) {
+    // ---------------- short-block MDCTs in binary32: 16 blocks of 64 samples, a 16-point transform each ----------------
+    // input idx of a block: idx < 32 -> E[32 blk + idx] (the block before, windowed W[i]; the overlap for block 0),
+    // else H[32 blk + idx - 32].  Point k = r + 4 bitrev2(j) at position j, i = 2 k (mdct.js:76-105 with N = 64).
+    int eb = s_eb0, hb = s_hb0, r2 = s_r2;
+    asm volatile("" : "+v"(eb), "+v"(hb), "+v"(r2));
+    {
+      const int pt = (int)offsetof(C1DevTables, pre32_64) + 4 * r2;
+      const v2f t0 = table_f2(RT, pt), t1 = table_f2(RT, pt + 64), t2 = table_f2(RT, pt + 32), t3 = table_f2(RT, pt + 96);
+      // position 0: i = r2 (first half), 2: i = r2 + 8 (first half), 1: i = r2 + 16 (second half), 3: i = r2 + 24 (second half)
+      const float a0 = mem[hb + 15 - r2], b0 = mem[hb + 16 + r2], c0 = mem[eb + 16 + r2], d0 = mem[eb + 15 - r2];
+      const float a2 = mem[hb + 7 - r2], b2 = mem[hb + 24 + r2], c2 = mem[eb + 24 + r2], d2 = mem[eb + 7 - r2];
+      const float a1 = mem[eb + 31 - r2], b1 = mem[eb + r2], c1 = mem[hb + r2], d1 = mem[hb + 31 - r2];
+      const float a3 = mem[eb + 23 - r2], b3 = mem[eb + 8 + r2], c3 = mem[hb + 8 + r2], d3 = mem[hb + 23 - r2];
+      const v2f rm0 = pk_fma(V2(b0, d0), PMN, V2(a0, c0)), rm2 = pk_fma(V2(b2, d2), PMN, V2(a2, c2));   // (a + b, c - d)
+      const v2f rm1 = pk_fma(V2(b1, d1), PNM, V2(a1, c1)), rm3 = pk_fma(V2(b3, d3), PNM, V2(a3, c3));   // (a - b, c + d)
+      auto twiddle = [](v2f rm, v2f t) { const v2f u = rm.yx * (t.yy * PMN); return pk_fma(rm, t.xx, u); };
+      x[0] = twiddle(rm0, t0); x[1] = twiddle(rm1, t1); x[2] = twiddle(rm2, t2); x[3] = twiddle(rm3, t3);
+      v2f en2 = x[0] * x[0];
+#pragma unroll
+      for (int j = 1; j < 4; j++) en2 = pk_fma(x[j], x[j], en2);
+      // energy of the block's 16 points (four lanes), then the largest block of the row
+      float en = en2.x + en2.y;
+      en += dpp_read<0xB1>(en);
+      en += dpp_read<0x4E>(en);
+      en = fmaxf(en, dpp_read<0x141>(en));
+      zrow = fmaxf(en, dpp_read<0x140>(en));
+      const v2f u0 = x[0] + x[1], u1 = x[0] - x[1], u2 = x[2] + x[3], u3 = x[2] - x[3];
+      x[0] = u0 + u2;
+      x[2] = u0 - u2;
+      x[1] = pk_fma(u3.yx, PMN, u1);
+      x[3] = pk_fma(u3.yx, PNM, u1);
+    }
+    {
+      v2f *z = reinterpret_cast<v2f *>(mem);
+      int za = B0.za, zb = B0.zb, g3 = s_g & 3;
+      asm volatile("" : "+v"(za), "+v"(zb), "+v"(g3));
+      const int twb = (int)offsetof(C1DevTables, r4b) + 24 * g3;
+      const v2f wBa = table_f2(RT, twb), wBb = table_f2(RT, twb + 8), wBc = table_f2(RT, twb + 16);
+      const int po = (int)offsetof(C1DevTables, pre32_64) + 8 * g3;
+      const v2f p0 = table_f2(RT, po), p1 = table_f2(RT, po + 32), p2 = table_f2(RT, po + 64), p3 = table_f2(RT, po + 96);
+      __syncthreads();                                     // every lane has read its inputs: the points may overwrite them
+      float4 *dst = reinterpret_cast<float4 *>(z + za);
+      dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+      dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+      __syncthreads();
+      const v2f *p = z + zb;
+      x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
+      radix4_round(x, wBa, wBb, wBc);
+      __syncthreads();
+      float *coefw = mem + kR2;
+      int c0i = s_c0;
+      asm volatile("" : "+v"(c0i));
+      const bool band0 = B0.band0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const v2f t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
+        const int e0 = c0i + 8 * j, e1 = (c0i | 31) - ((c0i & 31) + 8 * j);     // 32 blk + 2 i  and  32 blk + 31 - 2 i
+        const v2f u = x[j].yx * (t.yy * PMN);
+        const v2f o = pk_fma(x[j], t.xx, u);
+        coefw[band0 ? e0 : e1] = -o.x;
+        coefw[band0 ? e1 : e0] = o.y;
+      }
+    }
+    __syncthreads();
+
+    }
     // ---------------- the bound, coefficients out, scale-factor indices with their guard ----------------
     const int64_t unit = f * L.channels + ch;
     {
@@ -423,12 +548,16 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       dst[64 + lane] = src[64 + lane];
     }
     // eps_b = cz_b Z_b + cw_b W + cl_b L + eabs  (DESIGN.md 3b); Z_b^2 = energy of the band's pre-twiddled points
+    // (short blocks: of the block with the most energy; the coefficients then belong to 16-point transforms)
     const float Z0 = __builtin_amdgcn_sqrtf(lane_value(zrow, 0)), Z1 = __builtin_amdgcn_sqrtf(lane_value(zrow, 16));
-    const float Z2 = __builtin_amdgcn_sqrtf(lane_value(zrow, 32) + lane_value(zrow, 48));
+    const float Z2 = __builtin_amdgcn_sqrtf(SHORT ? fmaxf(lane_value(zrow, 32), lane_value(zrow, 48)) : lane_value(zrow, 32) + lane_value(zrow, 48));
     const float eabs = T->spec_eabs;
-    const float e0 = __builtin_fmaf(T->spec_cz[0], Z0, __builtin_fmaf(T->spec_cw[0], W, __builtin_fmaf(T->spec_cl[0], Lw, eabs)));
-    const float e1 = __builtin_fmaf(T->spec_cz[1], Z1, __builtin_fmaf(T->spec_cw[1], W, __builtin_fmaf(T->spec_cl[1], Lw, eabs)));
-    const float e2 = __builtin_fmaf(T->spec_cz[2], Z2, __builtin_fmaf(T->spec_cw[2], W, __builtin_fmaf(T->spec_cl[2], Lw, eabs)));
+    const float cz0 = SHORT ? T->spec_cz_short[0] : T->spec_cz[0], cz1 = SHORT ? T->spec_cz_short[1] : T->spec_cz[1], cz2 = SHORT ? T->spec_cz_short[2] : T->spec_cz[2];
+    const float cw0 = SHORT ? T->spec_cw_short[0] : T->spec_cw[0], cw1 = SHORT ? T->spec_cw_short[1] : T->spec_cw[1], cw2 = SHORT ? T->spec_cw_short[2] : T->spec_cw[2];
+    const float cl0 = SHORT ? T->spec_cl_short[0] : T->spec_cl[0], cl1 = SHORT ? T->spec_cl_short[1] : T->spec_cl[1], cl2 = SHORT ? T->spec_cl_short[2] : T->spec_cl[2];
+    const float e0 = __builtin_fmaf(cz0, Z0, __builtin_fmaf(cw0, W, __builtin_fmaf(cl0, Lw, eabs)));
+    const float e1 = __builtin_fmaf(cz1, Z1, __builtin_fmaf(cw1, W, __builtin_fmaf(cl1, Lw, eabs)));
+    const float e2 = __builtin_fmaf(cz2, Z2, __builtin_fmaf(cw2, W, __builtin_fmaf(cl2, Lw, eabs)));
     bool unstable;
     {
       SfLong SFL = SFL0;
@@ -467,10 +596,12 @@ void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const ui
   hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, (unsigned long long)units, redo_count);
 }
 
-void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, hipStream_t stream) {
-  static const int slots = c1k_wave_slots(k_analysis_spec);
+void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, bool all_short, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_analysis_spec<false>);
   C1EncodeLaunch L = L0;
   L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
   const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
-  hipLaunchKernelGGL(k_analysis_spec, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+  const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
+  if (all_short) hipLaunchKernelGGL((k_analysis_spec<true>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_analysis_spec<false>), grid, block, 0, stream, L);
 }

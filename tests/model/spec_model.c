@@ -27,10 +27,10 @@ static f2 TW2[256];                             /* radix-2 twiddles fl32(fft_tw[
 
 /* coefficients of the bound, as build_spec_tables() in carta1_amd/csrc/c1_api.hip computes them:
  * eps_b = cz_b Z_b + cw_b W + cl_b L + eabs */
-static float CZ[3], CW[3], CL[3], EABS;
+static float CZ[3], CW[3], CL[3], EABS, CZS[3], CWS[3], CLS[3];
 
 void spec_model_init(const float *even_taps, const double *window, const double *fwd64, const double *fwd256,
-                     const double *fwd512, const double *fft_w /* 8 x (cos,sin) */, const float *coef /* cz[3] cw[3] cl[3] eabs */) {
+                     const double *fwd512, const double *fft_w /* 8 x (cos,sin) */, const float *coef /* cz[3] cw[3] cl[3] eabs, then the same three triples for short blocks */) {
   memcpy(E32, even_taps, sizeof E32);
   for (int i = 0; i < 32; i++) W32[i] = (float)window[i];
   for (int i = 0; i < 16; i++) { PRE64[i].x = (float)fwd64[2 * i]; PRE64[i].y = (float)fwd64[2 * i + 1]; }
@@ -61,6 +61,7 @@ void spec_model_init(const float *even_taps, const double *window, const double 
     }
   for (int b = 0; b < 3; b++) { CZ[b] = coef[b]; CW[b] = coef[3 + b]; CL[b] = coef[6 + b]; }
   EABS = coef[9];
+  for (int b = 0; b < 3; b++) { CZS[b] = coef[10 + b]; CWS[b] = coef[13 + b]; CLS[b] = coef[16 + b]; }
 }
 
 typedef struct {
@@ -166,8 +167,51 @@ static void mdct_long_f32(const float *in, int N, float *out, float *lane_energy
   }
 }
 
-/* one all-long frame: pcm[512] -> coefs[512] (bands 1, 2 reversed as the reference stores them), eps[3] */
-void spec_model_frame(spec_state *s, const float *pcm, float *coefs, float *eps, float *bands_out) {
+/* one 64-sample MDCT (16-point transform) in binary32: in64 = the block's input, out = 32 coefficients (not reversed);
+ * lane_energy[0..3] = the partial energies of the four lanes that share the block */
+static void mdct_short_f32(const float *in, float *out, float *lane_energy) {
+  const int n4 = 16, n34 = 48, n2 = 32, nfft = 16;
+  f2 z[16];
+  for (int g = 0; g < 4; g++) {
+    const int r = bitrev(g, 2), q = 4;
+    f2 x[4];
+    float enx = 0, eny = 0;
+    for (int j = 0; j < 4; j++) {
+      const int jp = ((j & 1) << 1) | (j >> 1);
+      const int k = r + q * jp, i = 2 * k;
+      float rr, mm;
+      if (i < n4) { rr = in[n34 - 1 - i] + in[n34 + i]; mm = in[n4 + i] - in[n4 - 1 - i]; }
+      else { rr = in[n34 - 1 - i] - in[i - n4]; mm = in[n4 + i] + in[5 * n4 - 1 - i]; }
+      const f2 t = PRE64[k];
+      x[j].x = fmaf(rr, t.x, mm * t.y);
+      x[j].y = fmaf(mm, t.x, -(rr * t.y));
+      enx = j == 0 ? x[j].x * x[j].x : fmaf(x[j].x, x[j].x, enx);
+      eny = j == 0 ? x[j].y * x[j].y : fmaf(x[j].y, x[j].y, eny);
+    }
+    lane_energy[g] = enx + eny;
+    const f2 t0 = cadd(x[0], x[1]), t1 = csub(x[0], x[1]), t2 = cadd(x[2], x[3]), t3 = csub(x[2], x[3]);
+    f2 y1 = {t1.x + t3.y, t1.y - t3.x}, y3 = {t1.x - t3.y, t1.y + t3.x};
+    z[4 * g] = cadd(t0, t2); z[4 * g + 1] = y1; z[4 * g + 2] = csub(t0, t2); z[4 * g + 3] = y3;
+  }
+  for (int k = 0; k < 4; k++) {
+    f2 *p = z + k;
+    const f2 x0 = p[0], y1 = cmul(p[4], TWA[3 + k]), y2 = cmul(p[8], TWB[3 + k]), y3 = cmul(p[12], TWAB[3 + k]);
+    const f2 t0 = cadd(x0, y1), t1 = csub(x0, y1), t2 = cadd(y2, y3), t3 = csub(y2, y3);
+    p[0] = cadd(t0, t2);
+    p[8] = csub(t0, t2);
+    p[4].x = t1.x + t3.y; p[4].y = t1.y - t3.x;
+    p[12].x = t1.x - t3.y; p[12].y = t1.y + t3.x;
+  }
+  for (int i = 0; i < nfft; i++) {
+    const f2 t = PRE64[i];
+    out[2 * i] = -fmaf(z[i].x, t.x, z[i].y * t.y);
+    out[n2 - 1 - 2 * i] = fmaf(z[i].y, t.x, -(z[i].x * t.y));
+  }
+}
+
+/* one frame: pcm[512] -> coefs[512] (bands 1, 2 reversed as the reference stores them), eps[3].
+ * all_short = 0: fixed block modes [0,0,0]; 1: every band in short blocks */
+void spec_model_frame(spec_state *s, const float *pcm, float *coefs, float *eps, float *bands_out, int all_short) {
   float w1[46 + 512], low1[256], high1[256], w2[46 + 256], band[512];
   float lane[64];
   memcpy(w1, s->d1, sizeof s->d1);
@@ -204,30 +248,51 @@ void spec_model_frame(spec_state *s, const float *pcm, float *coefs, float *eps,
   float zen[3];
   for (int b = 0; b < 3; b++) {
     const int len = b == 2 ? 256 : 128, N = 2 * len, ws = b == 2 ? 112 : 48, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-    float in[512], spec[256], le[32];
-    memset(in, 0, sizeof in);
-    memcpy(in + ws, s->ov[b], 32 * sizeof(float));
-    memcpy(in + ws + 32, band + off, (size_t)len * sizeof(float));
-    for (int i = 0; i < 32; i++) {
-      const float v = band[off + len - 32 + i];
-      s->ov[b][i] = W32[i] * v;
-      in[ws + 32 + len - 32 + i] = v * W32[31 - i];
+    if (!all_short) {
+      float in[512], spec[256], le[32];
+      memset(in, 0, sizeof in);
+      memcpy(in + ws, s->ov[b], 32 * sizeof(float));
+      memcpy(in + ws + 32, band + off, (size_t)len * sizeof(float));
+      for (int i = 0; i < 32; i++) {
+        const float v = band[off + len - 32 + i];
+        s->ov[b][i] = W32[i] * v;
+        in[ws + 32 + len - 32 + i] = v * W32[31 - i];
+      }
+      mdct_long_f32(in, N, spec, le);
+      float rows[32];
+      memset(rows, 0, sizeof rows);
+      memcpy(rows, le, (size_t)(N / 16) * sizeof(float));
+      zen[b] = b == 2 ? row_sum(rows) + row_sum(rows + 16) : row_sum(rows);
+      if (b == 0) memcpy(coefs, spec, 128 * sizeof(float));
+      else for (int i = 0; i < len; i++) coefs[off + i] = spec[len - 1 - i];
+    } else {
+      /* E[s] = W[s & 31] x[s] behind the previous frame's overlap, H[s] = x[s] W[31 - (s & 31)] (encoder.js:269-307) */
+      float E[32 + 256], H[256];
+      memcpy(E, s->ov[b], 32 * sizeof(float));
+      for (int i = 0; i < len; i++) { E[32 + i] = W32[i & 31] * band[off + i]; H[i] = band[off + i] * W32[31 - (i & 31)]; }
+      memcpy(s->ov[b], E + len, 32 * sizeof(float));
+      float zmax = 0.0f;
+      for (int q = 0; q < len / 32; q++) {
+        float in[64], spec[32], le[4];
+        memcpy(in, E + 32 * q, 32 * sizeof(float));
+        memcpy(in + 32, H + 32 * q, 32 * sizeof(float));
+        mdct_short_f32(in, spec, le);
+        const float blk = (le[0] + le[1]) + (le[2] + le[3]);
+        zmax = fmaxf(zmax, blk);
+        for (int i = 0; i < 32; i++) coefs[off + 32 * q + i] = b == 0 ? spec[i] : spec[31 - i];
+      }
+      zen[b] = zmax;
     }
-    mdct_long_f32(in, N, spec, le);
-    float rows[32];
-    memset(rows, 0, sizeof rows);
-    memcpy(rows, le, (size_t)(N / 16) * sizeof(float));
-    zen[b] = b == 2 ? row_sum(rows) + row_sum(rows + 16) : row_sum(rows);
-    if (b == 0) memcpy(coefs, spec, 128 * sizeof(float));
-    else for (int i = 0; i < len; i++) coefs[off + i] = spec[len - 1 - i];
   }
   /* the bound; the kernel takes the square roots with v_sqrt_f32 (1 ulp), which the bound's theta covers */
-  for (int b = 0; b < 3; b++) eps[b] = fmaf(CZ[b], sqrtf(zen[b]), fmaf(CW[b], W, fmaf(CL[b], L, EABS)));
+  for (int b = 0; b < 3; b++)
+    eps[b] = all_short ? fmaf(CZS[b], sqrtf(zen[b]), fmaf(CWS[b], W, fmaf(CLS[b], L, EABS)))
+                       : fmaf(CZ[b], sqrtf(zen[b]), fmaf(CW[b], W, fmaf(CL[b], L, EABS)));
 }
 
-void spec_model_stream(const float *pcm, long frames, float *coefs, float *eps, float *bands) {
+void spec_model_stream(const float *pcm, long frames, float *coefs, float *eps, float *bands, int all_short) {
   spec_state s;
   spec_state_init(&s);
   for (long f = 0; f < frames; f++)
-    spec_model_frame(&s, pcm + 512 * f, coefs + 512 * f, eps + 3 * f, bands ? bands + 512 * f : 0);
+    spec_model_frame(&s, pcm + 512 * f, coefs + 512 * f, eps + 3 * f, bands ? bands + 512 * f : 0, all_short);
 }

@@ -29,14 +29,14 @@ def lib():
         L = C.CDLL(SO)
         fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
         L.spec_model_init.argtypes = [fp, dp, dp, dp, dp, dp, fp]
-        L.spec_model_stream.argtypes = [fp, C.c_long, fp, fp, fp]
+        L.spec_model_stream.argtypes = [fp, C.c_long, fp, fp, fp, C.c_int]
         t = O.golden_tables()
         d = lambda hs: np.array([O.h2d(x) for x in hs], dtype=np.float64)
         even = np.array([O.h2f(x) for x in t['qmf_even_f32']], dtype=np.float32)
         win = d(t['window_short_f64'])
         f64, f256, f512 = (d(t['mdct_sincos_f64'][k]) for k in ('fwd64', 'fwd256', 'fwd512'))
         fw = np.array([[O.h2d(a) for a in t['fft_w_f64'][str(1 << (s + 1))]] for s in range(8)], dtype=np.float64).ravel()
-        coef = bound_coefficients(f256, f512)
+        coef = bound_coefficients(f256, f512, f64)
         L.spec_model_init(even.ctypes.data_as(fp), win.ctypes.data_as(dp), f64.ctypes.data_as(dp), f256.ctypes.data_as(dp),
                           f512.ctypes.data_as(dp), fw.ctypes.data_as(dp), coef.ctypes.data_as(fp))
         _lib = L
@@ -50,14 +50,16 @@ def _round_up_f32(x):
     return f
 
 
-def bound_coefficients(f256, f512):
-    """cz[3], cw[3], cl[3], eabs exactly as build_spec_tables (c1_api.hip) computes them."""
+def bound_coefficients(f256, f512, f64):
+    """cz[3], cw[3], cl[3], eabs, then the triples for short blocks, exactly as build_spec_tables (c1_api.hip) computes them."""
     u = 2.0 ** -24 * THETA
     s256 = max(f256[2 * i] ** 2 + f256[2 * i + 1] ** 2 for i in range(64))
     s512 = max(f512[2 * i] ** 2 + f512[2 * i + 1] ** 2 for i in range(128))
     ka64 = KA_POST + KA_ROUND_A + 2 * KA_ROUND4 + KA_PRE
     ka128 = ka64 + KA_ROUND2
-    out = np.zeros(10, dtype=np.float32)
+    s64 = max(f64[2 * i] ** 2 + f64[2 * i + 1] ** 2 for i in range(16))
+    ka16 = KA_POST + KA_ROUND_A + KA_ROUND4 + KA_PRE
+    out = np.zeros(19, dtype=np.float32)
     for b in range(3):
         n, sg2 = (128, s512) if b == 2 else (64, s256)
         out[b] = _round_up_f32(u * (ka128 if b == 2 else ka64) * np.sqrt(sg2 * n))
@@ -67,30 +69,38 @@ def bound_coefficients(f256, f512):
         else:
             out[3 + b], out[6 + b] = _round_up_f32(gb * GH * GQ), _round_up_f32(gb * (7 * GH + GQ))
     out[9] = 2.0 ** -70
+    for b in range(3):
+        out[10 + b] = _round_up_f32(u * ka16 * np.sqrt(s64 * 16))
+        gs = u * s64 * np.sqrt(2.0 * 16)
+        if b == 2:
+            out[13 + b], out[16 + b] = _round_up_f32(gs * (5 * GH + GQ)), 0.0
+        else:
+            out[13 + b], out[16 + b] = _round_up_f32(gs * GH * GQ), _round_up_f32(gs * (7 * GH + GQ))
     return out
 
 
-def run(pcm):
-    """pcm: float32 mono stream (multiple of 512).  Returns coefs [frames,512], eps [frames,3], bands [frames,512]."""
+def run(pcm, all_short=False):
+    """pcm: float32 mono stream (multiple of 512).  Returns coefs [frames,512], eps [frames,3], bands [frames,512].
+    all_short: every band in short blocks (any non-zero fixed block modes) instead of [0,0,0]."""
     pcm = np.ascontiguousarray(pcm, dtype=np.float32)
     frames = len(pcm) // 512
     fp = C.POINTER(C.c_float)
     co = np.zeros((frames, 512), dtype=np.float32)
     ep = np.zeros((frames, 3), dtype=np.float32)
     bd = np.zeros((frames, 512), dtype=np.float32)
-    lib().spec_model_stream(pcm.ctypes.data_as(fp), frames, co.ctypes.data_as(fp), ep.ctypes.data_as(fp), bd.ctypes.data_as(fp))
+    lib().spec_model_stream(pcm.ctypes.data_as(fp), frames, co.ctypes.data_as(fp), ep.ctypes.data_as(fp), bd.ctypes.data_as(fp), 1 if all_short else 0)
     return co, ep, bd
 
 
-def reference_coefs(pcm):
-    """The reference's coefficients for fixed block modes [0,0,0] (through the oracle's stage entry points)."""
+def reference_coefs(pcm, modes=(0, 0, 0)):
+    """The reference's coefficients for the given fixed block modes (through the oracle's stage entry points)."""
     pcm = np.ascontiguousarray(pcm, dtype=np.float32)
     L = O.lib()
     frames = len(pcm) // 512
     fp = C.POINTER(C.c_float)
     st = O.EncState()
     co = np.zeros((frames, 512), dtype=np.float32)
-    modes = (C.c_int * 3)(0, 0, 0)
+    modes = (C.c_int * 3)(*modes)
     b = np.zeros(512, dtype=np.float32)
     for f in range(frames):
         L.c1o_qmf_analysis_frame(C.byref(st), pcm[512 * f:].ctypes.data_as(fp), b.ctypes.data_as(fp))

@@ -24,8 +24,9 @@ def ctx():
     c.close()
 
 
-def spec_stages(ctx, chans):
+def spec_stages(ctx, chans, modes=(0, 0, 0)):
     import torch
+    import carta1_amd as c1
     frames = len(chans[0]) // 512
     dev = [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in chans]
     n = frames * len(chans)
@@ -33,17 +34,20 @@ def spec_stages(ctx, chans):
     eps = torch.zeros(n * 4, dtype=torch.float32, device='cuda')
     side = torch.zeros(n * 64, dtype=torch.uint8, device='cuda')
     torch.cuda.synchronize()
-    ctx.spec_stages_device([d.data_ptr() for d in dev], frames, coefs.data_ptr(), eps.data_ptr(), side.data_ptr())
+    ctx.spec_stages_device([d.data_ptr() for d in dev], frames, coefs.data_ptr(), eps.data_ptr(), side.data_ptr(),
+                           c1.EncoderOptions({'fixedBlockModes': list(modes)}))
     ctx.synchronize()
     return (coefs.cpu().numpy().reshape(frames, len(chans), 512), eps.cpu().numpy().reshape(frames, len(chans), 4),
             side.cpu().numpy().reshape(frames, len(chans), 64))
 
 
+@pytest.mark.parametrize('modes', [(0, 0, 0), (2, 2, 3)], ids=['long', 'short'])
 @pytest.mark.parametrize('name,pcm', list(signals()), ids=[s[0] for s in signals()])
-def test_kernel_equals_its_model_and_stays_within_its_bound(ctx, name, pcm):
+def test_kernel_equals_its_model_and_stays_within_its_bound(ctx, name, pcm, modes):
     other = O.gen_white(9, len(pcm))
-    co, eps, side = spec_stages(ctx, [pcm, other])
-    mco, meps, _ = M.run(pcm)
+    short = modes != (0, 0, 0)
+    co, eps, side = spec_stages(ctx, [pcm, other], modes)
+    mco, meps, _ = M.run(pcm, short)
     # frames are processed in runs of 64 with one warm-up frame: the first frame of a later run has seen one frame of
     # history where the model has seen the whole stream, which is the same for these feed-forward filters
     assert np.array_equal(co[:, 0], mco), np.argwhere(co[:, 0] != mco)[:4]
@@ -54,10 +58,11 @@ def test_kernel_equals_its_model_and_stays_within_its_bound(ctx, name, pcm):
     close = np.isclose(eps[:, 0, :3], meps, rtol=2e-6, atol=0) | ~ok
     assert close.all(axis=1).mean() > 0.9
     assert np.allclose(eps[:, 0, :3][ok], meps[ok], rtol=0.2, atol=0)
-    ref = M.reference_coefs(pcm)
+    ref = M.reference_coefs(pcm, modes)
     err = np.abs(co[:, 0].astype(np.float64) - ref.astype(np.float64))
     assert (err <= eps[:, 0, :3][:, BAND]).all()
-    assert np.array_equal(co[:, 1], M.run(other)[0])
+    assert np.array_equal(co[:, 1], M.run(other, short)[0])
+    assert (side[:, :, 52] == (modes[0] | modes[1] << 2 | modes[2] << 4)).all()
 
 
 def encode_both_ways(ctx, chans, opts):
@@ -71,28 +76,30 @@ def encode_both_ways(ctx, chans, opts):
     return exact, spec, units, redone
 
 
+@pytest.mark.parametrize('modes', [(0, 0, 0), (2, 2, 3)], ids=['long', 'short'])
 @pytest.mark.parametrize('name,pcm', list(signals()), ids=[s[0] for s in signals()])
-def test_speculative_encode_is_bit_identical(ctx, name, pcm):
+def test_speculative_encode_is_bit_identical(ctx, name, pcm, modes):
     import carta1_amd as c1
     other = O.gen_pinkT(5, len(pcm))
-    opts = c1.EncoderOptions(LONG)
+    opts = c1.EncoderOptions({'fixedBlockModes': list(modes)})
     exact, spec, units, redone = encode_both_ways(ctx, [pcm, other], opts)
     assert units == exact.shape[0]
     assert np.array_equal(exact, spec), np.nonzero((exact != spec).any(axis=1))[0][:8]
-    want, _ = O.encode_stream([pcm, other], fixed_modes=(0, 0, 0))
+    want, _ = O.encode_stream([pcm, other], fixed_modes=modes)
     assert np.array_equal(spec, want)
 
 
+@pytest.mark.parametrize('modes', [(0, 0, 0), (2, 2, 3)], ids=['long', 'short'])
 @pytest.mark.parametrize('bias', [0.5, 1.0, 2.0])
-def test_white_noise_redo_fraction_and_identity(ctx, bias):
+def test_white_noise_redo_fraction_and_identity(ctx, bias, modes):
     import carta1_amd as c1
     n = 4096 * 512
     chans = [O.gen_white(1, n), O.gen_white(2, n)]
-    opts = c1.EncoderOptions(dict(LONG, allocationBias=bias), biased_table=O.biased_table(bias))
+    opts = c1.EncoderOptions({'fixedBlockModes': list(modes), 'allocationBias': bias}, biased_table=O.biased_table(bias))
     exact, spec, units, redone = encode_both_ways(ctx, chans, opts)
     assert np.array_equal(exact, spec)
     assert units == 8192 and 0 < redone < 0.12 * units, (units, redone)      # ~5 % on white noise
-    want, _ = O.encode_stream([c[:512 * 512] for c in chans], fixed_modes=(0, 0, 0), bias=bias)
+    want, _ = O.encode_stream([c[:512 * 512] for c in chans], fixed_modes=modes, bias=bias)
     assert np.array_equal(spec[:1024], want)
 
 

@@ -35,10 +35,11 @@ def signals():
     yield 'rounding_bait', x
 
 
+@pytest.mark.parametrize('all_short', [False, True], ids=['long', 'short'])
 @pytest.mark.parametrize('name,pcm', list(signals()), ids=[s[0] for s in signals()])
-def test_bound_dominates_the_observed_error(name, pcm):
-    co, eps, _ = M.run(pcm)
-    ref = M.reference_coefs(pcm)
+def test_bound_dominates_the_observed_error(name, pcm, all_short):
+    co, eps, _ = M.run(pcm, all_short)
+    ref = M.reference_coefs(pcm, (2, 2, 3) if all_short else (0, 0, 0))
     err = np.abs(co.astype(np.float64) - ref.astype(np.float64))
     ratio = err / eps[:, BAND].astype(np.float64)
     assert np.isfinite(eps).all()
