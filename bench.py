@@ -370,8 +370,17 @@ def main():
         outp = [torch.empty(frames * 512, dtype=torch.float32, device=dev) for _ in range(2)]
         optr = [p.data_ptr() for p in outp]
         el, km = timed(lambda: ctx.decode_device(u1.data_ptr(), 2, frames, optr), 3, 1, ('decode',))
-        ex['config2_decode'] = {'value': frames * 3 / el, 'unit': 'stereo frames/s', 'kernel_ms_per_step': km['decode']['ms_per_step']}
-        del outp, u0, u1
+        ex['config2_decode'] = {'value': frames * 3 / el, 'unit': 'stereo frames/s', 'kernel_ms_per_step': km['decode']['ms_per_step'],
+                                'arithmetic': 'exact (bit-identical to the reference)'}
+        # the opt-in binary32 decoder: rate, and its distance from the exact decoder's PCM (which the tests pin to the oracle bit for bit)
+        exact_head = [p[:4096 * 512].clone() for p in outp]
+        ctx.set_decode_precision(True)
+        el, km = timed(lambda: ctx.decode_device(u1.data_ptr(), 2, frames, optr), 3, 1, ('decode',))
+        ctx.set_decode_precision(False)
+        d32 = float(np.sqrt(np.mean([((a - b[:4096 * 512]).double() ** 2).mean().item() for a, b in zip(exact_head, outp)])))
+        ex['config2_decode_binary32_opt_in'] = {'value': frames * 3 / el, 'unit': 'stereo frames/s', 'kernel_ms_per_step': km['decode']['ms_per_step'],
+                                                'pcm_rms_vs_exact_decoder_first_4096_frames': d32, 'allowed_rms': 1e-5}
+        del outp, u0, u1, exact_head
         # config 5: allocationBias x fixedBlockModes, 1 M frames each
         c5 = []
         for m5 in ([0, 0, 0], [2, 2, 3]):

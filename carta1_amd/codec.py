@@ -113,6 +113,10 @@ class Context:
         """0 = exact kernels only, 1 = adaptive (default), 2 = always speculate (include/carta1_hip.h)."""
         capi.check(capi.load().c1_ctx_set_speculation(self._h, int(mode)))
 
+    def set_decode_precision(self, binary32):
+        """False (default): bit-identical to the reference; True: binary32 arithmetic, PCM within rounding noise."""
+        capi.check(capi.load().c1_ctx_set_decode_precision(self._h, 1 if binary32 else 0))
+
     def speculation_stats(self, reset=False):
         """(units encoded through the speculative pass, units among them redone by the exact kernels)."""
         u, r = C.c_uint64(0), C.c_uint64(0)

@@ -135,6 +135,10 @@ void build_spec_tables(const c1_tables &t, C1DevTables *d) {
   }
   for (int k = 0; k < 64; k++) { d->r2d[k][0] = (float)tw[63 + k][0]; d->r2d[k][1] = (float)tw[63 + k][1]; }
   for (int i = 0; i < 64 * 16; i++) d->norm32[i] = (float)d->norm[i];
+  for (int i = 0; i < 16; i++) { d->inv32_64[i][0] = (float)t.mdct_inv64[2 * i]; d->inv32_64[i][1] = (float)t.mdct_inv64[2 * i + 1]; }
+  for (int i = 0; i < 64; i++) { d->inv32_256[i][0] = (float)t.mdct_inv256[2 * i]; d->inv32_256[i][1] = (float)t.mdct_inv256[2 * i + 1]; }
+  for (int i = 0; i < 128; i++) { d->inv32_512[i][0] = (float)t.mdct_inv512[2 * i]; d->inv32_512[i][1] = (float)t.mdct_inv512[2 * i + 1]; }
+  for (int i = 0; i < 256; i++) { d->tw32[i][0] = (float)tw[i][0]; d->tw32[i][1] = (float)tw[i][1]; }
   const double u = std::ldexp(1.0, -24) * kSpecTheta;
   const double ka64 = kSpecKAPost + kSpecKARoundA + 2 * kSpecKARound4 + kSpecKAPre;
   const double ka128 = ka64 + kSpecKARound2;
@@ -364,6 +368,7 @@ struct c1_ctx {
   uint32_t *d_redo[2] = {nullptr, nullptr};
   unsigned long long *d_spec_totals = nullptr;   // [0] units encoded speculatively, [1] units redone exactly
   int spec_mode = 1;                             // 0 exact only, 1 adaptive (default), 2 always speculate
+  bool decode_binary32 = false;                  // c1_ctx_set_decode_precision: opt-in binary32 decoder
   bool spec_tables_ok = false;
   double spec_last_fraction = 0.0;               // redo fraction seen by the previous speculative call (adaptive mode)
   int spec_exact_calls = 0;                      // calls sent down the exact path since that observation
@@ -872,6 +877,13 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
   return C1_OK;
 }
 
+int c1_ctx_set_decode_precision(c1_ctx *ctx, int binary32) {
+  if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
+  CTX_GUARD(ctx);
+  ctx->decode_binary32 = binary32 != 0;
+  return C1_OK;
+}
+
 int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset) {
   CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);
@@ -1202,7 +1214,7 @@ int c1_decode_device(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fr
     if ((uintptr_t)pcm[c] & 15) return fail(C1_ERR_ARG, "pcm[%d] must be 16-byte aligned on the device", c);
     L.pcm[c] = pcm[c];
   }
-  { ScopedTiming t(ctx, K_DECODE); c1k_launch_decode(L, ctx->stream); }
+  { ScopedTiming t(ctx, K_DECODE); c1k_launch_decode(L, ctx->decode_binary32, ctx->stream); }
   HIP_TRY(hipGetLastError());
   return C1_OK;
 }

@@ -43,6 +43,8 @@ struct C1DevTables {
   float r4c[16][3][2];       // radix-4 round over stages 16, 32: k -> wa = tw[15+k], wb = tw[31+k], fl32(wa*wb)
   float r2d[64][2];          // stage 64: fl32(tw[63+k])
   float norm32[64 * 16];     // fl32(norm)
+  float inv32_64[16][2], inv32_256[64][2], inv32_512[128][2];   // fl32 of the inverse MDCT tables (binary32 decode)
+  float tw32[256][2];        // fl32(fft_tw)
   // error-bound coefficients per band (rounded up): eps_b = cz*Z_b + cw*W + cl*L + eabs
   float spec_cz[4], spec_cw[4], spec_cl[4];
   float spec_cz_short[4], spec_cw_short[4], spec_cl_short[4];   // the same for a band coded with short blocks (16-point transforms)
@@ -143,7 +145,7 @@ void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
 void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream);
-void c1k_launch_decode(const C1DecodeLaunch &L, hipStream_t stream);
+void c1k_launch_decode(const C1DecodeLaunch &L, bool binary32, hipStream_t stream);   // binary32: opt-in, PCM within rounding noise of the reference
 // kind_mask: bit k = fill the 512-frame segments with (segment & 3) == k (15 = all)
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, int kind_mask, double amp, hipStream_t stream);
 void c1k_launch_generate_pink(const uint32_t *segment_states, int64_t frames, float *pcm, int kind_mask, hipStream_t stream);

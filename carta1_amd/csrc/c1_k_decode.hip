@@ -1,30 +1,83 @@
 // c1_k_decode.hip -- deserializeFrame + the decode() closure (decoder.js:408-411): one wave per run of units
+// k_decode<double>: the reference's arithmetic (binary64 operations, binary32 at every typed-array store): decoded PCM
+//                   bit-identical to the reference.
+// k_decode<float>:  the same computation in binary32 (opt-in, c1_ctx_set_decode_precision): no conversions, half the
+//                   LDS for the synthesis windows; the PCM differs from the reference's by rounding noise (RMS ~1e-8 at
+//                   full scale, against the 1e-5 the task allows; tests/test_gpu_decode32.py).
 #include "c1_device.h"
 
 namespace {
 
+template <typename R> struct Pair2;
+template <> struct Pair2<double> { typedef double2 type; };
+template <> struct Pair2<float> { typedef float2 type; };
+// (cos, sin) table pair at entry `index` of the double table at `base64` / its binary32 twin at `base32`
+template <typename R>
+__device__ __forceinline__ typename Pair2<R>::type table_pair_r(TablesRsrc RT, int offset) {
+  if constexpr (std::is_same<R, double>::value) return table_pair(RT, offset);
+  else {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(RT, offset, 0, 0);
+    float2 d;
+    __builtin_memcpy(&d, &v, sizeof d);
+    return d;
+  }
+}
+// one radix-2 butterfly of fft.js:46-60 in the arithmetic R (R = double: r2_butterfly of c1_device.h)
+template <typename R>
+__device__ __forceinline__ void r2_bf(float2 &e, float2 &o, const typename Pair2<R>::type w) {
+  const R er = e.x, ei = e.y, orr = o.x, oi = o.y;
+  const R xr = orr * w.x - oi * w.y;
+  const R xi = orr * w.y + oi * w.x;
+  e = make_float2((float)(er + xr), (float)(ei + xi));
+  o = make_float2((float)(er - xr), (float)(ei - xi));
+}
+
 // =====================================================================================================
 // k_decode : deserializeFrame + decode() closure (decoder.js:408-411)
 // =====================================================================================================
+template <typename R>
 struct alignas(16) DecodeLds {
-  double d1[46];        // stage-1 synthesis delay (qmfDelays.lowBand)
-  double d2[46];        // stage-2 synthesis delay (qmfDelays.midBand)
+  R d1[46];             // stage-1 synthesis delay (qmfDelays.lowBand)
+  R d2[46];             // stage-2 synthesis delay (qmfDelays.midBand)
   float dhi[39];        // high-band delay
   float tail[48];       // last 16 IMDCT samples per band (imdctOverlap tails, decoder.js:227-230)
   uint32_t words[56];   // the unit as big-endian words
   uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
-  double sf_tab[64];    // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
-  double inv_tab[16];   // coefficient would cost a cache round trip each)
+  R sf_tab[64];         // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
+  R inv_tab[16];        // coefficient would cost a cache round trip each)
   union alignas(16) {
     float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
     float band[512];    // reconstructed bands: born at the overlap-add
   } cb;
   union alignas(16) {
     struct { union alignas(16) { float2 z[320]; } zz; alignas(16) float mid[512]; } m;   // IMDCT: points (4 pad per 16), outputs
-    struct { alignas(16) double w2[454]; } q2;                   // stage-2 synthesis work buffer (padded 2 per 4)
-    struct { alignas(16) double w1[698]; } q1;                   // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
+    struct { alignas(16) R w2[454]; } q2;                        // stage-2 synthesis work buffer (padded 2 per 4)
+    struct { alignas(16) R w1[698]; } q1;                        // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
   } u;
 };
+
+// qmf_synthesis_core of c1_device.h in the arithmetic R (same window layout, element type R)
+template <typename R, int D, int S>
+__device__ __forceinline__ void qmf_synth_r(const R *w, int lane, TablesPtr T, R (&s0)[D], R (&s1)[D]) {
+  if constexpr (std::is_same<R, double>::value) qmf_synthesis_core<D, S>(w, lane, T, s0, s1);
+  else {
+    typedef typename Pair2<R>::type pair;
+#pragma unroll
+    for (int d = 0; d < D; d++) s0[d] = s1[d] = 0.0f;
+#pragma unroll
+    for (int u = 0; u <= 22 + D; ++u) {
+      const pair x = *reinterpret_cast<const pair *>(w + (2 * D + 2) * lane + (2 * u + 2 * ((2 * u) >> S)));
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int j = u - d;
+        if (j >= 0 && j < 24) {
+          s0[d] = __builtin_fmaf(x.x, T->tap32[j], s0[d]);
+          s1[d] = __builtin_fmaf(x.y, T->tap32[23 - j], s1[d]);
+        }
+      }
+    }
+  }
+}
 
 __device__ __forceinline__ uint32_t get_bits_be(const uint32_t *words, int pos, int nbits) {
   // unpackBits (bitstream.js:49-70): stops at the end of the 212-byte buffer and returns what it has
@@ -46,7 +99,10 @@ struct IMixGeometry {
   int post_tab[4], ox[4], oy[4];
   bool is_long, band2;
 };
+template <typename R>
 __device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes &M) {
+  constexpr bool F32 = std::is_same<R, float>::value;
+  constexpr int kPair = F32 ? 8 : 16;                          // bytes per (cos, sin) / twiddle pair
   IMixGeometry G;
   const int band = lane < 16 ? 0 : (lane < 32 ? 1 : 2);
   const int g = lane - (band == 0 ? 0 : (band == 1 ? 16 : 32));
@@ -55,9 +111,11 @@ __device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes
   const int r = lng ? bitrev(g, band == 2 ? 5 : 4) : bitrev(g & 3, 2);
   const int blk = lng ? 0 : (g >> 2);
   const int obase = (band == 0 ? 0 : (band == 1 ? 128 : 256)) + 32 * blk;       // coefficients in, samples out
-  const int tab_base = lng ? (band == 2 ? (int)offsetof(C1DevTables, mdct_inv512) : (int)offsetof(C1DevTables, mdct_inv256))
-                           : (int)offsetof(C1DevTables, mdct_inv64);
-  const int tw_base = (int)offsetof(C1DevTables, fft_tw);
+  const int tab_base = F32 ? (lng ? (band == 2 ? (int)offsetof(C1DevTables, inv32_512) : (int)offsetof(C1DevTables, inv32_256))
+                                  : (int)offsetof(C1DevTables, inv32_64))
+                           : (lng ? (band == 2 ? (int)offsetof(C1DevTables, mdct_inv512) : (int)offsetof(C1DevTables, mdct_inv256))
+                                  : (int)offsetof(C1DevTables, mdct_inv64));
+  const int tw_base = F32 ? (int)offsetof(C1DevTables, tw32) : (int)offsetof(C1DevTables, fft_tw);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int jp = ((j & 1) << 1) | (j >> 1);
@@ -65,23 +123,23 @@ __device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes
     const int j0 = 2 * i, j1 = n2 - 1 - 2 * i;
     G.ja[j] = obase + (band > 0 ? n2 - 1 - j0 : j0);
     G.jb[j] = obase + (band > 0 ? n2 - 1 - j1 : j1);
-    G.pre_tab[j] = tab_base + 16 * i;
+    G.pre_tab[j] = tab_base + kPair * i;
   }
   const int pbase = band == 0 ? 0 : (band == 1 ? 64 : 128);
   G.za = zslot(pbase + 4 * g);
   G.zb = zslot(pbase + 16 * (g >> 2) + (g & 3));
-  G.twb = tw_base + 16 * (3 + (g & 3));
+  G.twb = tw_base + kPair * (3 + (g & 3));
   G.zc = zslot(pbase + 64 * (g >> 4) + (g & 15));
-  G.twc = tw_base + 16 * (15 + (g & 15));
+  G.twc = tw_base + kPair * (15 + (g & 15));
   G.zd = zslot(128 + (g & 31));
-  G.twd = tw_base + 16 * (63 + (g & 31));
+  G.twd = tw_base + kPair * (63 + (g & 31));
   G.is_long = lng;
   G.band2 = band == 2;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int i = lng ? (band == 2 ? g + (j == 1 ? 64 : (j == 2 ? 32 : (j == 3 ? 96 : 0))) : g + 16 * j) : (g & 3) + 4 * j;
     const int idx = (i < nfft / 2) ? 2 * i : (2 * (i - nfft / 2) + nfft);
-    G.post_tab[j] = tab_base + 16 * i;
+    G.post_tab[j] = tab_base + kPair * i;
     G.ox[j] = obase + n2 - 1 - idx;
     G.oy[j] = obase + idx;
   }
@@ -89,24 +147,30 @@ __device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes
 }
 
 // coef: 512 dequantized coefficients; z: 320 slots; mid: 512 outputs.  any_long / band2_long are wave-uniform.
+template <typename RT_>
 __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mid, const IMixGeometry &G, bool any_long,
                                          bool band2_long, TablesPtr T, TablesRsrc R) {
+  typedef RT_ real;
+  typedef typename Pair2<real>::type pair;
+  constexpr bool F32 = std::is_same<real, float>::value;
+  constexpr int kPair = F32 ? 8 : 16;
   float2 x[4];
   {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const double r = -(double)coef[G.ja[j]], mm = -(double)coef[G.jb[j]];
-      const double2 t = table_pair(R, G.pre_tab[j]);
-      x[j] = make_float2(f32(mm * t.y + r * t.x), f32(mm * t.x - r * t.y));
+      const real r = -(real)coef[G.ja[j]], mm = -(real)coef[G.jb[j]];
+      const pair t = table_pair_r<real>(R, G.pre_tab[j]);
+      x[j] = make_float2((float)(mm * t.y + r * t.x), (float)(mm * t.x - r * t.y));
     }
-    const double2 w0 = make_double2(T->fft_tw[0][0], T->fft_tw[0][1]);
-    const double2 w1 = make_double2(T->fft_tw[1][0], T->fft_tw[1][1]);
-    const double2 w2 = make_double2(T->fft_tw[2][0], T->fft_tw[2][1]);
-    if (__all(r2_unit_ok(x[0], x[1]) && r2_unit_ok(x[2], x[3]))) { r2_butterfly_unit(x[0], x[1]); r2_butterfly_unit(x[2], x[3]); }
-    else { r2_butterfly(x[0], x[1], w0); r2_butterfly(x[2], x[3], w0); }
-    if (__all(r2_unit_ok(x[0], x[2]))) r2_butterfly_unit(x[0], x[2]);
-    else r2_butterfly(x[0], x[2], w1);
-    r2_butterfly(x[1], x[3], w2);
+    pair w0, w1, w2;
+    w0.x = (real)T->fft_tw[0][0]; w0.y = (real)T->fft_tw[0][1];
+    w1.x = (real)T->fft_tw[1][0]; w1.y = (real)T->fft_tw[1][1];
+    w2.x = (real)T->fft_tw[2][0]; w2.y = (real)T->fft_tw[2][1];
+    if (F32 || __all(r2_unit_ok(x[0], x[1]) && r2_unit_ok(x[2], x[3]))) { r2_butterfly_unit(x[0], x[1]); r2_butterfly_unit(x[2], x[3]); }
+    else { r2_bf<real>(x[0], x[1], w0); r2_bf<real>(x[2], x[3], w0); }
+    if (F32 || __all(r2_unit_ok(x[0], x[2]))) r2_butterfly_unit(x[0], x[2]);
+    else r2_bf<real>(x[0], x[2], w1);
+    r2_bf<real>(x[1], x[3], w2);
     float4 *dst = reinterpret_cast<float4 *>(z + G.za);
     dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
     dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
@@ -114,55 +178,59 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
   __syncthreads();
   {
     float2 *p = z + G.zb;
-    const double2 wa = table_pair(R, G.twb), wb = table_pair(R, G.twb + 64), wc = table_pair(R, G.twb + 128);
+    const pair wa = table_pair_r<real>(R, G.twb), wb = table_pair_r<real>(R, G.twb + 4 * kPair), wc = table_pair_r<real>(R, G.twb + 8 * kPair);
     x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
-    r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
-    r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+    r2_bf<real>(x[0], x[1], wa); r2_bf<real>(x[2], x[3], wa);
+    r2_bf<real>(x[0], x[2], wb); r2_bf<real>(x[1], x[3], wc);
     if (G.is_long) { p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3]; }
   }
   if (any_long) {
     __syncthreads();
     if (G.is_long) {
       float2 *p = z + G.zc;
-      const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
+      const pair wa = table_pair_r<real>(R, G.twc), wb = table_pair_r<real>(R, G.twc + 16 * kPair), wc = table_pair_r<real>(R, G.twc + 32 * kPair);
       x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
-      r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wa);
-      r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
+      r2_bf<real>(x[0], x[1], wa); r2_bf<real>(x[2], x[3], wa);
+      r2_bf<real>(x[0], x[2], wb); r2_bf<real>(x[1], x[3], wc);
       if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
     }
     if (band2_long) {
       __syncthreads();
       if (G.band2) {
         const float2 *p = z + G.zd;
-        const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);
+        const pair wa = table_pair_r<real>(R, G.twd), wb = table_pair_r<real>(R, G.twd + 32 * kPair);
         x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
-        r2_butterfly(x[0], x[1], wa); r2_butterfly(x[2], x[3], wb);
+        r2_bf<real>(x[0], x[1], wa); r2_bf<real>(x[2], x[3], wb);
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const double2 t = table_pair(R, G.post_tab[j]);
-    const double rr = x[j].x, ii = x[j].y;
-    mid[G.ox[j]] = f32(rr * t.x + ii * t.y);                // mdct.js:177-208
-    mid[G.oy[j]] = f32(rr * t.y - ii * t.x);
+    const pair t = table_pair_r<real>(R, G.post_tab[j]);
+    const real rr = x[j].x, ii = x[j].y;
+    mid[G.ox[j]] = (float)(rr * t.x + ii * t.y);            // mdct.js:177-208
+    mid[G.oy[j]] = (float)(rr * t.y - ii * t.x);
   }
 }
 
-__global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
-  __shared__ DecodeLds S;
+template <typename R>
+__global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) void k_decode(C1DecodeLaunch L) {
+  typedef R real;
+  typedef typename Pair2<R>::type pair;
+  constexpr bool F32 = std::is_same<R, float>::value;
+  __shared__ DecodeLds<R> S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
   const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * L.run_frames;
   float *__restrict__ pcm = L.pcm[ch];
 
-  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
+  for (int i = lane; i < 46; i += 64) { S.d1[i] = 0; S.d2[i] = 0; }
   for (int i = lane; i < 39; i += 64) S.dhi[i] = 0.0f;
   for (int i = lane; i < 48; i += 64) S.tail[i] = 0.0f;
   if (lane < 3) S.words[53 + lane] = 0u;
-  S.sf_tab[lane] = C1_TABLES(L.tables)->scale_factors[lane];
-  if (lane < 16) S.inv_tab[lane] = C1_TABLES(L.tables)->inv_range[lane];
+  S.sf_tab[lane] = (real)C1_TABLES(L.tables)->scale_factors[lane];
+  if (lane < 16) S.inv_tab[lane] = (real)C1_TABLES(L.tables)->inv_range[lane];
   // lane-only geometry, computed once per wave
   uint32_t slot[8];                                  // BFU(6) | index inside the BFU(5) << 6 | short-block position(9) << 11
 #pragma unroll
@@ -172,7 +240,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     slot[m] = (uint32_t)b | ((uint32_t)j << 6) | ((uint32_t)(kStartShort[b] + j) << 11);
   }
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
-  const IMixGeometry IGL = imix_geometry(lane0, FrameModes{0, 0, 0});   // all-long frames
+  const IMixGeometry IGL = imix_geometry<R>(lane0, FrameModes{0, 0, 0});   // all-long frames
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
@@ -218,12 +286,15 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       const int32_t range = (1 << (bits - 1)) - 1;
       float v = 0.0f;                                                                               // quantization.js:65-78
       if (sf != 0) {
+        if constexpr (F32) v = ((float)q * S.sf_tab[sf]) * S.inv_tab[bits - 1];
+        else {
         const double a = (double)q * S.sf_tab[sf];
         if (T->dq_fast) {
           const double y = S.inv_tab[bits - 1], q0 = a * y;
           v = f32(__builtin_fma(__builtin_fma(-q0, (double)range, a), y, q0));                  // == a / range (checked on the host)
         } else {
           v = f32(a / (double)range);
+        }
         }
       }
       const int mode = sb >= 36 ? m2 : (sb >= 20 ? m1 : m0);
@@ -234,18 +305,18 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     // ---------------- imdctStage (decoder.js:116-330) ----------------
     float *mid = S.u.m.mid;
     if (all_long) {
-      imdct_r4(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT);
+      imdct_r4<R>(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT);
       __syncthreads();
       // overlap-add of the first 32 samples of every band (mdct.js:230-245 via decoder.js:203-232) ...
       if (lane < 32) {
         const bool lo = lane < 16;
         const int i = lo ? lane : 31 - lane;
-        const double wa = T->window[i], wb = T->window[31 - i];       // w1 = W[i], w2 = W[31-i]
+        const real wa = F32 ? (real)T->win32[i] : (real)T->window[i], wb = F32 ? (real)T->win32[31 - i] : (real)T->window[31 - i];   // w1 = W[i], w2 = W[31-i]
 #pragma unroll
         for (int b = 0; b < 3; b++) {
           const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
-          const double pv = S.tail[16 * b + i], cv = mid[off + 15 - i];
-          S.cb.band[off + lane] = lo ? f32(pv * wb - cv * wa) : f32(pv * wa + cv * wb);
+          const real pv = S.tail[16 * b + i], cv = mid[off + 15 - i];
+          S.cb.band[off + lane] = lo ? (float)(pv * wb - cv * wa) : (float)(pv * wa + cv * wb);
         }
       }
       // ... the rest of the band is invBuf[16 .. S-16) (decoder.js:215-221)
@@ -256,8 +327,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
       if (lane < 56) *reinterpret_cast<float4 *>(&S.cb.band[256 + 32 + 4 * lane]) = *reinterpret_cast<const float4 *>(&mid[256 + 16 + 4 * lane]);
     } else {
     FrameModes M{m0, m1, m2};
-    const IMixGeometry IG = imix_geometry(lane, M);
-    imdct_r4(S.cb.coef, S.u.m.zz.z, mid, IG, m0 == 0 || m1 == 0 || m2 == 0, m2 == 0, T, RT);
+    const IMixGeometry IG = imix_geometry<R>(lane, M);
+    imdct_r4<R>(S.cb.coef, S.u.m.zz.z, mid, IG, m0 == 0 || m1 == 0 || m2 == 0, m2 == 0, T, RT);
     __syncthreads();
     // overlap-add (mdct.js:230-245 via decoder.js:203-232 long / :262-300 short)
 #pragma unroll
@@ -274,12 +345,12 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
         const float *prev = (q == 0) ? (S.tail + 16 * b) : (mid + off + 32 * (q - 1) + 16);
         const float *curr = mid + off + 32 * q;
         if (k < 16) {
-          const double w1 = T->window[k], w2 = T->window[31 - k];
-          v = f32((double)prev[k] * w2 - (double)curr[15 - k] * w1);
+          const real w1 = F32 ? (real)T->win32[k] : (real)T->window[k], w2 = F32 ? (real)T->win32[31 - k] : (real)T->window[31 - k];
+          v = (float)((real)prev[k] * w2 - (real)curr[15 - k] * w1);
         } else {
           const int i = 31 - k;
-          const double w1 = T->window[i], w2 = T->window[31 - i];
-          v = f32((double)prev[i] * w1 + (double)curr[15 - i] * w2);
+          const real w1 = F32 ? (real)T->win32[i] : (real)T->window[i], w2 = F32 ? (real)T->win32[31 - i] : (real)T->window[31 - i];
+          v = (float)((real)prev[i] * w1 + (real)curr[15 - i] * w2);
         }
       } else {
         v = mid[off + k - 16];                     // long block only: invBuf[16 .. S-16)
@@ -296,7 +367,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
     __syncthreads();
 
     // ---------------- qmfSynthesisStage (decoder.js:349-389) ----------------
-    double *w2 = S.u.q2.w2, *w1 = S.u.q1.w1;
+    real *w2 = S.u.q2.w2, *w1 = S.u.q1.w1;
     // high band delay compensation (:360-366): delayed high sample j = j < 39 ? previous tail : band2[j-39]
     float hi4[4];
 #pragma unroll
@@ -312,15 +383,16 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
 #pragma unroll
       for (int d = 0; d < 2; d++) {
         const int i = 2 * lane + d;
-        const double l = S.cb.band[i], h = S.cb.band[128 + i];
-        *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 2 * i)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
+        const real l = S.cb.band[i], h = S.cb.band[128 + i];
+        pair v2; v2.x = (real)(float)((real)0.5 * (l + h)); v2.y = (real)(float)((real)0.5 * (l - h));
+        *reinterpret_cast<pair *>(&w2[pidx<2>(46 + 2 * i)]) = v2;
       }
       __syncthreads();
       if (lane < 39) S.dhi[lane] = keep;
     }
     {
-      double s0[2], s1[2];
-      qmf_synthesis_core<2, 2>(w2, lane, T, s0, s1);
+      real s0[2], s1[2];
+      qmf_synth_r<R, 2, 2>(w2, lane, T, s0, s1);
       if (lane < 46) S.d2[lane] = w2[pidx<2>(256 + lane)];
       __syncthreads();                                    // w1 reuses the memory of w2 from here on
       if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
@@ -330,21 +402,22 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
           const int sidx = 4 * lane + 2 * d + t;          // sample index in the 256-sample low band
-          const double l = (double)f32(t == 0 ? s1[d] : s0[d]);
-          const double h = hi4[2 * d + t];
-          *reinterpret_cast<double2 *>(&w1[pidx<3>(46 + 2 * sidx)]) = make_double2((double)f32(0.5 * (l + h)), (double)f32(0.5 * (l - h)));
+          const real l = (real)(float)(t == 0 ? s1[d] : s0[d]);
+          const real h = hi4[2 * d + t];
+          pair v2; v2.x = (real)(float)((real)0.5 * (l + h)); v2.y = (real)(float)((real)0.5 * (l - h));
+          *reinterpret_cast<pair *>(&w1[pidx<3>(46 + 2 * sidx)]) = v2;
         }
       }
     }
     __syncthreads();
     {
-      double s0[4], s1[4];
-      qmf_synthesis_core<4, 3>(w1, lane, T, s0, s1);
+      real s0[4], s1[4];
+      qmf_synth_r<R, 4, 3>(w1, lane, T, s0, s1);
       if (lane < 46) S.d1[lane] = w1[pidx<3>(512 + lane)];
       if (emit) {
         float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512 + 8 * lane);
-        dst[0] = make_float4(f32(s1[0]), f32(s0[0]), f32(s1[1]), f32(s0[1]));
-        dst[1] = make_float4(f32(s1[2]), f32(s0[2]), f32(s1[3]), f32(s0[3]));
+        dst[0] = make_float4((float)s1[0], (float)s0[0], (float)s1[1], (float)s0[1]);
+        dst[1] = make_float4((float)s1[2], (float)s0[2], (float)s1[3], (float)s0[3]);
       }
     }
     __syncthreads();
@@ -353,10 +426,12 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_decode(C1DecodeLaunch L) {
 
 }  // namespace
 
-void c1k_launch_decode(const C1DecodeLaunch &L0, hipStream_t stream) {
-  static const int slots = c1k_wave_slots(k_decode);
+void c1k_launch_decode(const C1DecodeLaunch &L0, bool binary32, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_decode<double>);
   C1DecodeLaunch L = L0;
   L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
   const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
-  hipLaunchKernelGGL(k_decode, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L);
+  const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
+  if (binary32) hipLaunchKernelGGL((k_decode<float>), grid, block, 0, stream, L);
+  else hipLaunchKernelGGL((k_decode<double>), grid, block, 0, stream, L);
 }

@@ -119,6 +119,12 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode);
  * created (or since the last call with reset != 0); synchronises the context's stream */
 int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset);
 
+/* Decoder arithmetic.  0 (default): the reference's -- binary64 operations, binary32 at every typed-array store --
+ * decoded PCM bit-identical to the reference.  1: the same computation in binary32 throughout; the PCM then differs
+ * from the reference's by rounding noise (measured RMS < 1e-7 on full-scale material; the task statement allows 1e-5
+ * "otherwise").  Applies to every decode entry point of the context. */
+int c1_ctx_set_decode_precision(c1_ctx *ctx, int binary32);
+
 /* ---- encode: replaces the encode() frame closure body, encoder.js:438-450
  *      (qmfAnalysisStage :57-96, blockSelectorStage :111-152, mdctStage :170-349,
  *      quantizationStage :365-418) plus serializeFrame (serialization.js:41-98), batched ----- */
