@@ -463,7 +463,7 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
     HIP_TRY(hipMalloc(&ctx->d_side[p], (size_t)units * kSideBytes));
     HIP_TRY(hipMalloc(&ctx->d_alloc[p], (size_t)units * kAllocBytes));
     HIP_TRY(hipMalloc(&ctx->d_cand[p], (size_t)units * kCandidateBytes));
-    HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 7 + 4) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 8 + 4) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&ctx->d_eps[p], (size_t)units * kEpsFloats * sizeof(float)));
     HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units + 4) * sizeof(uint32_t)));
   }
@@ -617,6 +617,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.cand = ctx->d_cand[p];
     L.work_count = ctx->d_work[p];
     L.work_list = ctx->d_work[p] + 4;
+    L.sel_list = ctx->d_work[p] + 4 + (size_t)ctx->ws_units * 7;
     L.bands = bands ? bands + f0 * channels * 512 : nullptr;
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     const bool all_long = all_long_modes;
@@ -810,7 +811,7 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
     ctx->pipeline = pl ? atoi(pl) != 0 : false;   // measured: no gain while one kernel's grid already owns every CU's LDS
   }
   const char *env = getenv("C1_CHUNK_FRAMES");
-  ctx->chunk_frames = env ? atoll(env) : 524288;
+  ctx->chunk_frames = env ? atoll(env) : 1048576;
   if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
   // the allocation work list packs (unit << 3 | candidate) into 32 bits and unit lists are 32-bit: a chunk holds
   // fewer than 2^29 units, with room to spare
@@ -960,7 +961,7 @@ int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   L.channels = channels; L.frames = frames; L.halo_frames = halo_frames;
   L.tables = ctx->d_tables; L.opts = ctx->d_opts;
   L.coefs = ctx->d_coefs[0]; L.side = ctx->d_side[0]; L.alloc = ctx->d_alloc[0]; L.cand = ctx->d_cand[0];
-  L.work_count = ctx->d_work[0]; L.work_list = ctx->d_work[0] + 4;
+  L.work_count = ctx->d_work[0]; L.work_list = ctx->d_work[0] + 4; L.sel_list = ctx->d_work[0] + 4 + (size_t)ctx->ws_units * 7;
   L.mags = mags;
   c1k_launch_detect(L, ctx->d_bands[0], ctx->d_feat[0], ctx->d_modes[0], ctx->d_lists[0], ctx->stream);
   if (modes) HIP_TRY(hipMemcpyAsync(modes, ctx->d_modes[0], (size_t)units, hipMemcpyDeviceToDevice, ctx->stream));

@@ -86,7 +86,8 @@ struct C1EncodeLaunch {
   uint8_t *alloc;    // frames*channels*32
   uint8_t *cand;     // frames*channels*kCandBytes: per-candidate totals and results
   uint32_t *work_list;   // frames*channels*7 entries (unit<<3 | candidate)
-  uint32_t *work_count;
+  uint32_t *work_count;  // [0] entries of work_list, [1] entries of sel_list
+  uint32_t *sel_list;    // units that kept more than the 52-BFU candidate alive: k_alloc_select picks among their results
   float *bands;      // optional tap (may be null)
   float *mags;       // optional tap of the transient detector's magnitude spectra, frames*channels*256 (64 | 64 | 128)
   uint8_t *units;    // frames*channels*212   (may be null for stage taps)

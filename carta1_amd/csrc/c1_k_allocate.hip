@@ -226,24 +226,37 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
                 (!(finite && t4 > total) ? 16u : 0u) | (!(finite && t5 > total) ? 32u : 0u) |
                 (!(finite && t6 > total) ? 64u : 0u);
   }
-  if (live) {
+  const bool finite52 = total < __builtin_huge_val();
+  if (live && survivors == 0) {
+    // nothing else can win: the 52-BFU candidate is the allocation (or the fallback when its total is not finite,
+    // bitallocation.js:132-139); no candidate record, no selection pass for this unit
+    uint64_t *dst = reinterpret_cast<uint64_t *>(L.alloc + unit * kAllocBytes);
+    if (finite52) { dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3 | (7ull << 60); }
+    else { dst[0] = 0; dst[1] = 0; dst[2] = 0; dst[3] = 1ull << 59; }
+  } else if (live) {
     uint8_t *base = L.cand + unit * kCandBytes;
     double *tot = reinterpret_cast<double *>(base);
 #pragma unroll
     for (int c = 0; c < 7; c++) tot[c] = __builtin_huge_val();
-    store_candidate(L.cand, unit, 7, total < __builtin_huge_val() ? total : __builtin_huge_val(), r0, r1, r2, r3);
+    store_candidate(L.cand, unit, 7, finite52 ? total : __builtin_huge_val(), r0, r1, r2, r3);
   }
-  // append the surviving (unit, candidate) pairs to the work list: one atomic per wave
+  // append the surviving (unit, candidate) pairs to the work list and the unit to the selection list: one atomic each per wave
   const int mine = live ? __popc(survivors) : 0;
   const int scan = wave_inclusive_scan(mine);
   const int wave_total = __builtin_amdgcn_readlane(scan, 63);
-  uint32_t base_idx = 0;
-  if (lane == 0 && wave_total > 0) base_idx = atomicAdd(L.work_count, (uint32_t)wave_total);
+  const uint64_t sel_mask = __builtin_amdgcn_ballot_w64(mine > 0);
+  uint32_t base_idx = 0, sel_base = 0;
+  if (lane == 0 && wave_total > 0) {
+    base_idx = atomicAdd(L.work_count, (uint32_t)wave_total);
+    sel_base = atomicAdd(L.work_count + 1, (uint32_t)__popcll(sel_mask));
+  }
   base_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_idx);
+  sel_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel_base);
   if (mine > 0) {
     uint32_t at = base_idx + (uint32_t)(scan - mine);
     for (int c = 0; c < 7; c++)
       if ((survivors >> c) & 1u) L.work_list[at++] = ((uint32_t)(unit - (int64_t)0) << 3) | (uint32_t)c;
+    L.sel_list[sel_base + (uint32_t)__popcll(sel_mask & ((1ull << lane) - 1ull))] = (uint32_t)unit;
   }
   }
 }
@@ -268,11 +281,11 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L) {
   }
 }
 
+// the units on the selection list (those with more than one candidate alive): smallest total, smallest count on ties
 __global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
-  const bool listed = L.unit_list != nullptr;
-  const int64_t units_total = listed ? (int64_t)*L.unit_count : L.frames * L.channels;
-  for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < units_total; pos += (int64_t)gridDim.x * 256) {
-  const int64_t unit = listed ? (int64_t)L.unit_list[pos] : pos;
+  const int64_t count = (int64_t)L.work_count[1];
+  for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < count; pos += (int64_t)gridDim.x * 256) {
+  const int64_t unit = (int64_t)L.sel_list[pos];
   const uint8_t *base = L.cand + unit * kCandBytes;
   const double *tot = reinterpret_cast<const double *>(base);
   double best = __builtin_huge_val();
@@ -299,11 +312,11 @@ __global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
   const bool listed = L.unit_list != nullptr;            // the list's length is only known on the device: bounded grids stride over it
-  (void)hipMemsetAsync(L.work_count, 0, sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(L.work_count, 0, 2 * sizeof(uint32_t), stream);
   const int64_t first_blocks = listed ? std::min<int64_t>((units + 63) / 64, 256 * 12) : (units + 63) / 64;
   hipLaunchKernelGGL(k_alloc_first, dim3((unsigned)first_blocks), dim3(C1_WAVE), 0, stream, L);
   const int64_t rest_blocks = std::min<int64_t>((units * 7 + 63) / 64, 256 * 10);
   hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest_blocks), dim3(C1_WAVE), 0, stream, L);
-  const int64_t select_blocks = listed ? std::min<int64_t>((units + 255) / 256, 2048) : (units + 255) / 256;
+  const int64_t select_blocks = std::min<int64_t>((units + 255) / 256, 1024);      // strides over the selection list
   hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)select_blocks), dim3(256), 0, stream, L);
 }
