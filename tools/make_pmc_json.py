@@ -32,8 +32,15 @@ def collect(d):
 def main():
     from bench import source_sha
     per = collect(sys.argv[1])
-    out = {'note': __doc__.split('\n\n', 1)[1].replace('\n', ' '), 'units_per_launch': 1048576, 'source_sha': source_sha()}
-    for key, kern in (('analysis', 'k_analysis_spec'), ('pack', 'k_pack<true, true>'), ('allocate', 'k_alloc_first'),
+    # sound units one full-batch launch covers: the profiled bench line says how many frames and launches a step had
+    units = 1048576
+    try:
+        b = json.loads(open(os.path.join(sys.argv[1], 'bench_under_rocprof.json')).read().strip().splitlines()[-1])
+        units = int(b['roofline']['stereo_frames_per_launch'] * b['config']['channels'])
+    except Exception:   # noqa: BLE001
+        pass
+    out = {'note': __doc__.split('\n\n', 1)[1].replace('\n', ' '), 'units_per_launch': units, 'source_sha': source_sha()}
+    for key, kern in (('analysis', 'k_analysis_spec<false>'), ('pack', 'k_pack<true, true>'), ('allocate', 'k_alloc_first'),
                       ('redo', 'k_analysis_fast<true>')):
         c = per.get(kern)
         if not c:
