@@ -16,6 +16,18 @@ with open(out + '/kernel_stats.txt', 'w') as w:
     for r in csv.DictReader(open(f[0])):
         w.write('%-70s calls %5s avg_us %10.1f total_ms %9.2f  %s%%\n' % (r['Name'].replace('(anonymous namespace)::', '')[:70], r['Calls'],
                 float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6, r['Percentage']))
+# the same per kernel without the warm-up step's launch (bench.py times steps 2..N only): what `roofline.avg_launch_ms` must agree with
+import collections
+per = collections.defaultdict(list)
+t = glob.glob(out + '/trace/**/*kernel_trace.csv', recursive=True)
+for r in csv.DictReader(open(t[0])):
+    per[r['Kernel_Name'].replace('(anonymous namespace)::', '')].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+with open(out + '/kernel_stats.txt', 'a') as w:
+    w.write('\ntimed steps only (first launch of each kernel dropped when it has exactly steps + warmup = 4 launches):\n')
+    for k, v in sorted(per.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+        if len(v) == 4:
+            d = [x[1] for x in sorted(v)[1:]]
+            w.write('%-70s calls %5d avg_us %10.1f\n' % (k[:70], len(d), sum(d) / len(d) / 1e3))
 print(open(out + '/kernel_stats.txt').read())
 PY
 i=0
