@@ -221,6 +221,10 @@ class Context:
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
             C.c_void_p(mags_ptr), C.c_void_p(modes_ptr)))
 
+    def libm_device(self, fn, in_ptr, out_ptr, n):
+        """Math.log / exp / log1p / log10 (fn 0..3) as the detector's kernels evaluate them, on n device doubles."""
+        capi.check(capi.load().c1_libm_device(self._h, fn, C.c_void_p(in_ptr), C.c_void_p(out_ptr), n))
+
     def spec_stages_device(self, pcm_ptrs, frames, coefs_ptr, eps_ptr, side_ptr, options=None, halo_frames=0):
         """The speculative binary32 analysis alone: coefficients, their proven error bounds, scale-factor indices."""
         opts = (options or EncoderOptions({'fixedBlockModes': [0, 0, 0]})).to_c()

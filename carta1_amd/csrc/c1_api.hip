@@ -969,6 +969,16 @@ int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   return C1_OK;
 }
 
+int c1_libm_device(c1_ctx *ctx, int fn, const double *in, double *out, int64_t n) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (fn < 0 || fn > 3 || n < 0 || (n > 0 && (!in || !out))) return fail(C1_ERR_ARG, "bad fn / n / NULL argument");
+  c1k_launch_libm(fn, in, out, n, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
 int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                           const c1_encode_options *opts, float *coefs, float *eps, uint8_t *side) {
   CTX_GUARD(ctx);

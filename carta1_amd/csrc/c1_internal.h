@@ -142,6 +142,7 @@ constexpr int kFeatureWsDoubles = 20;
 // lists_ws: 4 + 2 * units uint32 (two counts, then the all-long and the mixed unit list)
 void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
                        hipStream_t stream);
+void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list

@@ -33,6 +33,185 @@ struct alignas(16) DetectLds {
 
 __device__ __forceinline__ int tslot(int pos) { return pos + (pos >> 3); }
 
+// =====================================================================================================
+// Math.log / exp / log1p / log10 as the reference's engine evaluates them (transient.js:129, :137, :185, :211).
+// V8 (src/base/ieee754.cc) ports the published fdlibm algorithms; they are not correctly rounded, so another libm
+// returns a neighbouring double for 1-7 % of the arguments.  These restate the same algorithms operation for
+// operation (contraction is off in this file); tests/test_gpu_parity.py checks them bit for bit against V8's results
+// (tests/golden/libm_v8_*.bin) through c1_libm_device.
+// =====================================================================================================
+__device__ __forceinline__ double js_with_hi(double x, int hi) { return __hiloint2double(hi, __double2loint(x)); }
+constexpr double kLn2Hi = 6.93147180369123816490e-01, kLn2Lo = 1.90821492927058770002e-10, kTwo54 = 1.80143985094819840000e+16;
+
+// e_log.c.  The four return expressions of the main path are one: with dk = 0 the k != 0 forms reduce to the k == 0 ones
+// exactly (0 - (a - f) == f - a, P + 0 == P), and the two mantissa ranges differ in two operands.
+__device__ __forceinline__ double js_log(double x) {
+  constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                   Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                   Lg7 = 1.479819860511658591e-01;
+  int hx = __double2hiint(x), k = 0;
+  if (hx < 0x00100000) {
+    if (((hx & 0x7fffffff) | __double2loint(x)) == 0) return -__builtin_huge_val();
+    if (hx < 0) return __builtin_nan("");
+    k = -54; x *= kTwo54; hx = __double2hiint(x);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  const int i = (hx + 0x95f64) & 0x100000;
+  x = js_with_hi(x, hx | (i ^ 0x3ff00000));
+  k += (i >> 20);
+  const double f = x - 1.0, dk = (double)k;
+  const double hi = dk * kLn2Hi, lo = dk * kLn2Lo;
+  if ((0x000fffff & (2 + hx)) < 3) {
+    if (f == 0.0) return hi + lo;
+    const double R = f * f * (0.5 - 0.33333333333333333 * f);
+    return hi - ((R - lo) - f);
+  }
+  const double s = f / (2.0 + f), z = s * s, w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const bool mid = ((hx - 0x6147a) | (0x6b851 - hx)) > 0;
+  const double hfsq = 0.5 * f * f;
+  const double P = s * ((mid ? hfsq : f) + (mid ? R : -R));
+  const double Q = mid ? hfsq - (P + lo) : P - lo;
+  return hi - (Q - f);
+}
+
+// e_exp.c
+__device__ double js_exp(double x) {
+  constexpr double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02, invln2 = 1.44269504088896338700e+00,
+                   P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                   P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08, E = 2.718281828459045,
+                   huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302, two1023 = 8.988465674311579539e307;
+  double hi = 0.0, lo = 0.0;
+  int k = 0;
+  uint32_t hx = (uint32_t)__double2hiint(x);
+  const int xsb = (int)(hx >> 31);
+  hx &= 0x7fffffffu;
+  if (hx >= 0x40862E42u) {
+    if (hx >= 0x7ff00000u) {
+      if (((hx & 0xfffffu) | (uint32_t)__double2loint(x)) != 0) return x + x;
+      return xsb == 0 ? x : 0.0;
+    }
+    if (x > o_threshold) return huge * huge;
+    if (x < u_threshold) return twom1000 * twom1000;
+  }
+  if (hx > 0x3fd62e42u) {
+    if (hx < 0x3FF0A2B2u) {
+      if (x == 1.0) return E;
+      hi = x - (xsb ? -kLn2Hi : kLn2Hi); lo = xsb ? -kLn2Lo : kLn2Lo; k = 1 - xsb - xsb;
+    } else {
+      k = (int)(invln2 * x + (xsb ? -0.5 : 0.5));
+      const double t = (double)k;
+      hi = x - t * kLn2Hi;
+      lo = t * kLn2Lo;
+    }
+    x = hi - lo;
+  } else if (hx < 0x3e300000u) {
+    if (huge + x > 1.0) return 1.0 + x;
+  }
+  const double t = x * x;
+  const double twopk = __hiloint2double(0x3ff00000 + ((k >= -1021 ? k : k + 1000) << 20), 0);
+  const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  if (k >= -1021) {
+    if (k == 1024) return y * 2.0 * two1023;
+    return y * twopk;
+  }
+  return y * twopk * twom1000;
+}
+
+// s_log1p.c
+__device__ double js_log1p(double x) {
+  constexpr double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+                   Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+                   Lp7 = 1.479819860511658591e-01;
+  double f = 0.0, c = 0.0, u;
+  int hu = 0, k = 1;
+  const int hx = __double2hiint(x), ax = hx & 0x7fffffff;
+  if (hx < 0x3FDA827A) {
+    if (ax >= 0x3ff00000) {
+      if (x == -1.0) return -__builtin_huge_val();
+      return __builtin_nan("");
+    }
+    if (ax < 0x3e200000) {
+      if (kTwo54 + x > 0.0 && ax < 0x3c900000) return x;
+      return x - x * x * 0.5;
+    }
+    if (hx > 0 || hx <= (int)0xbfd2bec4) { k = 0; f = x; hu = 1; }
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  if (k != 0) {
+    if (hx < 0x43400000) {
+      u = 1.0 + x;
+      hu = __double2hiint(u);
+      k = (hu >> 20) - 1023;
+      c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+      c /= u;
+    } else {
+      u = x;
+      hu = __double2hiint(u);
+      k = (hu >> 20) - 1023;
+      c = 0.0;
+    }
+    hu &= 0x000fffff;
+    if (hu < 0x6a09e) {
+      u = js_with_hi(u, hu | 0x3ff00000);
+    } else {
+      k += 1;
+      u = js_with_hi(u, hu | 0x3fe00000);
+      hu = (0x00100000 - hu) >> 2;
+    }
+    f = u - 1.0;
+  }
+  const double hfsq = 0.5 * f * f, dk = (double)k;
+  if (hu == 0) {
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      c += dk * kLn2Lo;
+      return dk * kLn2Hi + c;
+    }
+    const double R = hfsq * (1.0 - 0.66666666666666666 * f);
+    if (k == 0) return f - R;
+    return dk * kLn2Hi - ((R - (dk * kLn2Lo + c)) - f);
+  }
+  const double s = f / (2.0 + f), z = s * s;
+  const double R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  return dk * kLn2Hi - ((hfsq - (s * (hfsq + R) + (dk * kLn2Lo + c))) - f);
+}
+
+// e_log10.c as V8 carries it (log of the normalised argument, then the exponent in two pieces)
+__device__ double js_log10(double x) {
+  constexpr double ivln10 = 4.34294481903251816668e-01, log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+  int hx = __double2hiint(x), k = 0;
+  uint32_t lx = (uint32_t)__double2loint(x);
+  if (hx < 0x00100000) {
+    if (((hx & 0x7fffffff) | lx) == 0) return -__builtin_huge_val();
+    if (hx < 0) return __builtin_nan("");
+    k = -54; x *= kTwo54; hx = __double2hiint(x); lx = (uint32_t)__double2loint(x);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  if (hx == 0x3ff00000 && lx == 0) return 0.0;
+  k += (hx >> 20) - 1023;
+  const int i = (int)(((uint32_t)k & 0x80000000u) >> 31);
+  hx = (hx & 0x000fffff) | ((0x3ff - i) << 20);
+  const double y = (double)(k + i);
+  x = __hiloint2double(hx, (int)lx);
+  const double z = y * log10_2lo + ivln10 * js_log(x);
+  return z + y * log10_2hi;
+}
+
+__global__ void k_libm_tap(int fn, const double *__restrict__ in, double *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  out[i] = fn == 0 ? js_log(x) : (fn == 1 ? js_exp(x) : (fn == 2 ? js_log1p(x) : js_log10(x)));
+}
+
 // Round A of the transient FFT (performFFT, transient.js:17-35): real input, stages h = 1, 2, 4 on the points at
 // bit-reversed positions 8g..8g+7.  Seven of the twelve butterflies have the twiddle (1, 0); when every sample is
 // finite, not -0 and small enough not to overflow they are exact as Float32 adds (see r2_unit_ok), and the
@@ -245,7 +424,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
         valid[i] = cm > 1e-10;
         S.u.tt.term[0][g] = diff > 0 ? diff : 0.0;            // spectral flux terms (transient.js:96-106)
         S.u.tt.term[1][g] = cm * cm;                          // energy terms (exact product)
-        S.u.tt.term[2][g] = valid[i] ? log(cm) : 0.0;         // flatness terms (transient.js:126-133)
+        S.u.tt.term[2][g] = valid[i] ? js_log(cm) : 0.0;         // flatness terms (transient.js:126-133)
         S.u.tt.term[3][g] = valid[i] ? cm : 0.0;
       }
       int nv_all = 0;
@@ -299,7 +478,7 @@ __device__ __forceinline__ BandFeatures band_features(const double *s, int nv) {
   r.flux = s_flux / norm;
   r.flat = 0.0;                                          // calculateSpectralFlatness :120-141
   if (nv > 0) {
-    const double gm = exp(s_log / (double)nv), am = s_lin / (double)nv;
+    const double gm = js_exp(s_log / (double)nv), am = s_lin / (double)nv;
     r.flat = am > 1e-10 ? gm / am : 0.0;
   }
   const double tot = s_lo + s_hi;                        // calculateHighFrequencyRatio :149-164
@@ -326,10 +505,10 @@ __device__ __forceinline__ int detect_decide_unit(const double *__restrict__ fea
     }
     const double ce = c.energy > 1e-10 ? c.energy : 1e-10;     // calculateEnergyChange :172-189
     const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
-    const double db = 10.0 * log10(ce / pe);
+    const double db = 10.0 * js_log10(ce / pe);
     const double e_change = db > 0 ? db : 0.0;
     const double flat_c = sqrt(fabs(c.flat - prev_flat));       // calculateTransientScore :197-226
-    const double hf_c = log1p(fabs(c.hf - prev_hf) * 10.0) / log1p10;
+    const double hf_c = js_log1p(fabs(c.hf - prev_hf) * 10.0) / log1p10;
     const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
     const double score = (c.flux + flat_c + hf_c + e_c) / 4.0;
     const int mode = (score > threshold) ? (b + 1 > 2 ? b + 1 : 2) : 0;   // encoder.js:143
@@ -522,4 +701,9 @@ void c1k_launch_detect(const C1EncodeLaunch &L0, float *bands_ws, double *feat_w
   const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
   hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
   hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+}
+
+void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_libm_tap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, in, out, n);
 }

@@ -226,6 +226,11 @@ int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
 int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                             const c1_encode_options *opts, float *mags, uint8_t *modes);
 
+/* Test tap: Math.log (fn 0), Math.exp (1), Math.log1p (2), Math.log10 (3) as the reference's engine evaluates them and as
+ * the detector's kernels use them (transient.js:129, :137, :185, :211; V8 src/base/ieee754.cc = fdlibm, not correctly
+ * rounded, so the algorithm itself is part of the parity contract).  in, out: n doubles, device pointers. */
+int c1_libm_device(c1_ctx *ctx, int fn, const double *in, double *out, int64_t n);
+
 /* The speculative binary32 analysis on its own (diagnostics; tests/test_gpu_spec.py checks the bound with it):
  * coefs: frames*channels*512 floats = the binary32 coefficients; eps: frames*channels*4 floats = the proven bound on
  * |coefficient - reference coefficient| for bands 0, 1, 2 and a flag word (non-zero bit pattern: a scale-factor

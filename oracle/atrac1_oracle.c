@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "c1o_tables.inc"
+#include "c1o_fdlibm.h"
 
 #define F32(x) ((float)(x))
 
@@ -236,6 +237,12 @@ static void fft_magnitudes(const float *x, int n, float *mag) {
   for (int i = 0; i < n / 2; i++) mag[i] = F32(sqrt((double)re[i] * re[i] + (double)im[i] * im[i]));
 }
 
+/* test tap: the engine's Math.log (0), exp (1), log1p (2), log10 (3) on an array (c1o_fdlibm.h) */
+void c1o_libm(int fn, const double *in, double *out, long n) {
+  for (long i = 0; i < n; i++)
+    out[i] = fn == 0 ? c1o_fd_log(in[i]) : (fn == 1 ? c1o_fd_exp(in[i]) : (fn == 2 ? c1o_fd_log1p(in[i]) : c1o_fd_log10(in[i])));
+}
+
 void c1o_transient_mags(const float bands[512], float mags[256]) {
   fft_magnitudes(bands, 128, mags);
   fft_magnitudes(bands + 128, 128, mags + 64);
@@ -249,13 +256,13 @@ static double flatness(const float *c, int n) {
   for (int i = 0; i < n; i++) {
     double m = fabs((double)c[i]);
     if (m > 1e-10) {
-      sum_log += log(m);
+      sum_log += c1o_fd_log(m); /* Math.log as V8 evaluates it: c1o_fdlibm.h */
       sum_lin += m;
       valid++;
     }
   }
   if (valid == 0) return 0;
-  double gm = exp(sum_log / valid), am = sum_lin / valid;
+  double gm = c1o_fd_exp(sum_log / valid), am = sum_lin / valid;
   return am > 1e-10 ? gm / am : 0;
 }
 
@@ -291,11 +298,11 @@ int c1o_detect_transient(const float *cur, const float *prev, int n, double thre
   }
   ce = ce > 1e-10 ? ce : 1e-10; /* Math.max(e, 1e-10) */
   pe = pe > 1e-10 ? pe : 1e-10;
-  double db = 10 * log10(ce / pe);
+  double db = 10 * c1o_fd_log10(ce / pe);
   double e_change = db > 0 ? db : 0;
   /* calculateTransientScore :197-226 */
   double flat_c = sqrt(flat_change);
-  double hf_c = log1p(hf_change * 10) / C1O_LOG1P_10;
+  double hf_c = c1o_fd_log1p(hf_change * 10) / C1O_LOG1P_10;
   double e_c = e_change / 30 < 1 ? e_change / 30 : 1;
   double score = (flux + flat_c + hf_c + e_c) / 4;
   return score > threshold;

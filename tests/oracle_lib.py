@@ -57,6 +57,8 @@ def lib():
         _lib.c1o_qmf_analysis_frame.argtypes = [C.POINTER(EncState), fp, fp]
         _lib.c1o_block_modes.argtypes = [C.POINTER(EncState), fp, C.POINTER(Options), ip]
         _lib.c1o_transient_mags.argtypes = [fp, fp]
+        _lib.c1o_libm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long]
+        _lib.c1o_libm.restype = None
         _lib.c1o_detect_transient.argtypes = [fp, fp, C.c_int, C.c_double]
         _lib.c1o_detect_transient.restype = C.c_int
         _lib.c1o_mdct_frame.argtypes = [C.POINTER(EncState), fp, ip, fp]
@@ -208,4 +210,15 @@ def pad_frames(x):
     n = (len(x) + 511) // 512 * 512
     out = np.zeros(n, dtype=np.float32)
     out[:len(x)] = x
+    return out
+
+
+LIBM_FUNCTIONS = ('log', 'exp', 'log1p', 'log10')
+
+
+def libm(name, x):
+    """Math.log / exp / log1p / log10 as the reference's engine evaluates them (oracle/c1o_fdlibm.h)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().c1o_libm(LIBM_FUNCTIONS.index(name), x.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)), x.size)
     return out

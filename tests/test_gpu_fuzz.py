@@ -81,3 +81,31 @@ def test_detector_taps_against_reference_magnitudes_and_decisions(ctx):
         for f in range(8):
             for b in range(3):
                 assert ((m[f] >> (2 * b)) & 3) in (0, 3 if b == 2 else 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fn,name', list(enumerate(O.LIBM_FUNCTIONS)))
+def test_engine_libm_on_the_device_matches_v8(ctx, fn, name):
+    """Math.log / exp / log1p / log10 inside the detector's kernels against V8's own results (tests/golden/libm_v8_*.bin,
+    tests/golden/gen/gen_libm.mjs): bit for bit on every vector, NaN for NaN.  The functions are not correctly rounded
+    (glibc differs from V8 on 1-7 % of these arguments), so this pins the algorithm, not just its accuracy."""
+    import torch
+    io = np.fromfile(os.path.join(G, 'libm_v8_%s.bin' % name), dtype='<f8').reshape(-1, 2)
+    x = torch.from_numpy(np.ascontiguousarray(io[:, 0])).cuda()
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    ctx.libm_device(fn, x.data_ptr(), y.data_ptr(), x.numel())
+    ctx.synchronize()
+    got, want = y.cpu().numpy(), np.ascontiguousarray(io[:, 1])
+    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (name, io[~same][:4], got[~same][:4])
+    # and the oracle's restatement on a denser set of detector-like arguments (Float32 magnitudes above 1e-10)
+    if name == 'log':
+        rng = np.random.default_rng(5)
+        m = np.exp(rng.uniform(np.log(1.0000001e-10), np.log(1e6), 1 << 20)).astype(np.float32).astype(np.float64)
+        x = torch.from_numpy(m).cuda()
+        y = torch.zeros_like(x)
+        torch.cuda.synchronize()
+        ctx.libm_device(0, x.data_ptr(), y.data_ptr(), x.numel())
+        ctx.synchronize()
+        assert np.array_equal(y.cpu().numpy().view(np.uint64), O.libm('log', m).view(np.uint64))
