@@ -288,6 +288,13 @@ int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
       return fail(C1_ERR_ARG, "fixed_block_modes[%d] = %d is outside 0..%d", b, m, b == 2 ? 3 : 2);
     d->modes[b] = m;
   }
+  {
+    // log2 of the biased table as a line in the index (exact for pow(2^(s/3-21), bias)); see C1DevEncOpts
+    const double l1 = std::log2(d->biased[1]), l63 = std::log2(d->biased[63]);
+    const double slope = (l63 - l1) / 62.0;
+    d->la_slope = (std::isfinite(slope) && std::isfinite(l1)) ? (float)slope : 0.0f;
+    d->la_off = (std::isfinite(slope) && std::isfinite(l1)) ? (float)(l1 - slope) : 0.0f;
+  }
   float pri[64 * 15];
   std::vector<float> uniq;
   for (int s = 1; s < 64; s++)

@@ -62,7 +62,10 @@ struct C1DevEncOpts {
   // when the rank order is the order of an integer form A*sfi - B*wl (wl >= 1) / A*sfi + C (wl == 0),
   // as it is for the usual biases, the kernels compute it instead of reading the table
   int32_t rank_affine, rank_a, rank_b, rank_c, rank_off;
-  int32_t pad2_[3];
+  // log2(biased[s]) ~ la_slope * s + la_off: only steers the multiplier search of the candidate bounds (k_alloc_bound);
+  // the bounds themselves are formed from `biased`, so an inexact fit costs pruning power, never correctness
+  float la_slope, la_off;
+  int32_t pad2_;
 };
 
 // ---- geometry ------------------------------------------------------------------------------------
@@ -71,7 +74,8 @@ constexpr int kRunFramesDecode = 64; // consecutive units of one channel decoded
 constexpr int kRunFramesLong = 64;   // same, in the all-long-blocks fast path
 constexpr int kSideBytes = 64;   // per unit: sfi[52], modes byte, pad
 constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallback flag
-constexpr int kCandidateBytes = 8 * 8 + 8 * 32;  // per unit: 8 totals + 8 results (bit allocation scratch)
+constexpr int kCandidateBytes = 8 * 8 + 8 * 32 + 8 * 8;  // per unit: 8 totals + 8 results + 8 lower bounds (bit allocation scratch)
+constexpr int kCandLbOffset = 8 * 8 + 8 * 32;
 constexpr int kEpsFloats = 4;    // per unit (speculative path): error bound of bands 0..2, flags
 
 struct C1EncodeLaunch {
@@ -85,8 +89,8 @@ struct C1EncodeLaunch {
   uint8_t *side;     // frames*channels*64
   uint8_t *alloc;    // frames*channels*32
   uint8_t *cand;     // frames*channels*kCandBytes: per-candidate totals and results
-  uint32_t *work_list;   // frames*channels*7 entries (unit<<3 | candidate)
-  uint32_t *work_count;  // [0] entries of work_list, [1] entries of sel_list
+  uint32_t *work_list;   // frames*channels*7 entries (unit<<3 | candidate): first-round heaps at [0, units), second round behind them
+  uint32_t *work_count;  // [0] first-round entries of work_list, [1] entries of sel_list, [2] second-round entries
   uint32_t *sel_list;    // units that kept more than the 52-BFU candidate alive: k_alloc_select picks among their results
   float *bands;      // optional tap (may be null)
   float *mags;       // optional tap of the transient detector's magnitude spectra, frames*channels*256 (64 | 64 | 128)

@@ -14,9 +14,17 @@ namespace {
 //                   addition is monotone, every term is >= 0, so the bound holds for the rounded sums too).
 //                   A candidate whose bound already exceeds the 52-BFU total can never win the strict `<`
 //                   comparison and is skipped; the others are appended to a work list.
+//   k_alloc_bound   one lane per unit that still has candidates alive: a second, much sharper lower bound for each of
+//                   them (Lagrangian relaxation of the greedy's knapsack, below), drops what that already excludes
+//                   and sends the most promising candidate of the unit to the first round of heaps.
 //   k_alloc_rest    one lane per work-list entry (unit, candidate): the same heap run.
+//   k_alloc_pick2   one lane per such unit: the candidates whose bound does not exceed the best total known now
+//                   (52 BFUs or the first-round result) go to the second round; the others can never win.
 //   k_alloc_select  one lane per unit: smallest total, smallest count on ties (:116-129), or the
 //                   fallback when no total is finite (:132-139).
+// On white noise 97 % of the units stop after k_alloc_first; stationary tonal material keeps all eight candidates
+// alive under the first bound (its upper BFUs are nearly silent, so dropping them costs nothing) and ran 8 heaps per
+// unit; with the second bound it runs 2.
 //
 // Heap entry (one 32-bit word, bit 31 clear):  rank(10) | size(5) | sfi(6) | wl(4) | bfu(6).
 // `rank` orders the Float32 priorities biasedSF[sfi]*DISTORTION_DELTA_FACTORS[wl]/WORD_LENGTH_DELTA_BITS[wl]
@@ -30,7 +38,8 @@ namespace {
 // heap frees, so when the loop ends slots [0, initial size) hold every BFU with its final word length.
 constexpr int kHeapSlotsPerLane = 52 + 2;   // + two zero sentinels behind the last slot
 constexpr uint32_t kLow = 0x1FFFFFu;
-constexpr int kCandBytes = kCandidateBytes;  // per unit: 8 totals (double) + 8 x 32-byte results
+constexpr int kCandBytes = kCandidateBytes;  // per unit: 8 totals (double) + 8 x 32-byte results + 8 lower bounds
+constexpr double kAlive = -1.0;              // total of a candidate that may still win and has not been evaluated (real totals are >= 0)
 
 __device__ __forceinline__ uint32_t heap_entry(uint32_t rank, int size, int s, int wl, int b) {
   return (rank << 21) | ((uint32_t)size << 16) | ((uint32_t)s << 10) | ((uint32_t)wl << 6) | (uint32_t)b;
@@ -234,42 +243,185 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
     if (finite52) { dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3 | (7ull << 60); }
     else { dst[0] = 0; dst[1] = 0; dst[2] = 0; dst[3] = 1ull << 59; }
   } else if (live) {
+    // totals of the other candidates: +inf = cannot win, kAlive = still possible and not evaluated yet
     uint8_t *base = L.cand + unit * kCandBytes;
     double *tot = reinterpret_cast<double *>(base);
 #pragma unroll
-    for (int c = 0; c < 7; c++) tot[c] = __builtin_huge_val();
+    for (int c = 0; c < 7; c++) tot[c] = ((survivors >> c) & 1u) ? kAlive : __builtin_huge_val();
     store_candidate(L.cand, unit, 7, finite52 ? total : __builtin_huge_val(), r0, r1, r2, r3);
   }
-  // append the surviving (unit, candidate) pairs to the work list and the unit to the selection list: one atomic each per wave
-  const int mine = live ? __popc(survivors) : 0;
-  const int scan = wave_inclusive_scan(mine);
-  const int wave_total = __builtin_amdgcn_readlane(scan, 63);
-  const uint64_t sel_mask = __builtin_amdgcn_ballot_w64(mine > 0);
-  uint32_t base_idx = 0, sel_base = 0;
-  if (lane == 0 && wave_total > 0) {
-    base_idx = atomicAdd(L.work_count, (uint32_t)wave_total);
-    sel_base = atomicAdd(L.work_count + 1, (uint32_t)__popcll(sel_mask));
-  }
-  base_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_idx);
+  // append the unit to the selection list: one atomic per wave
+  const uint64_t sel_mask = __builtin_amdgcn_ballot_w64(live && survivors != 0);
+  uint32_t sel_base = 0;
+  if (lane == 0 && sel_mask != 0) sel_base = atomicAdd(L.work_count + 1, (uint32_t)__popcll(sel_mask));
   sel_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel_base);
-  if (mine > 0) {
-    uint32_t at = base_idx + (uint32_t)(scan - mine);
-    for (int c = 0; c < 7; c++)
-      if ((survivors >> c) & 1u) L.work_list[at++] = ((uint32_t)(unit - (int64_t)0) << 3) | (uint32_t)c;
-    L.sel_list[sel_base + (uint32_t)__popcll(sel_mask & ((1ull << lane) - 1ull))] = (uint32_t)unit;
-  }
+  if (live && survivors != 0) L.sel_list[sel_base + (uint32_t)__popcll(sel_mask & ((1ull << lane) - 1ull))] = (uint32_t)unit;
   }
 }
 
-__global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L) {
+// =====================================================================================================
+// The second bound.  For a candidate that codes n BFUs with B = 1656 - 10 n bits, ANY word lengths wl_b that fit the
+// budget (sum size_b bits(wl_b) <= B) -- in particular the ones the greedy heap ends with -- satisfy, for every
+// multiplier lambda >= 0,
+//     sum_{b<n} D_b(wl_b)  >=  sum_{b<n} [D_b(wl_b) + lambda size_b bits(wl_b)] - lambda B
+//                          >=  sum_{b<n} min_wl [D_b(wl) + lambda size_b bits(wl)] - lambda B,
+// with D_b(0) = zeroBitDistortions[b] and D_b(wl) = biasedSF * 2^-bits * size the very terms calculateTotalDistortion adds
+// (bitallocation.js:157-190).  Adding the zero-bit terms of the BFUs the candidate does not code gives a lower bound
+// on its total for every lambda; it is sharpest near the multiplier at which the relaxed problem spends exactly B bits,
+// found by bisection on log2 lambda (the relaxed spend is a decreasing step function of it).  The inner minimum is
+// explicit: D + lambda size bits is convex in bits >= 2 (each further bit gains biasedSF 2^-(bits+1) per coefficient),
+// so its minimum over 2..16 bits sits at clamp(floor(log2(biasedSF / lambda)), 2, 16); the zero-bit term competes
+// separately because it is stored as a Float32.  Measured against the totals the heaps produce the bound is within
+// 2-4 % (tools/alloc_bound_sim.py).
+// Rounding: the reference's total is a sequential sum of at most 52 non-negative doubles, so it is at least
+// (1 - 51 * 2^-53) times the exact sum; our P = sum of minima and M = lambda B carry a few roundings each.  The bound
+// handed on is (P - M) - 2^-44 (P + M): three orders of magnitude more slack than all of that, and still 1e-13 of the
+// totals it is compared with.  A candidate is dropped only when this bound is strictly above a total that was really
+// computed, i.e. when it cannot even tie (:116-129 keeps the earlier candidate on ties).
+// =====================================================================================================
+__device__ __forceinline__ int relaxed_bits(float y) {      // word length in bits the relaxed problem gives a BFU with log2(biasedSF / lambda) = y
+  const int e = (int)__builtin_floorf(y);
+  const int bits = e < 2 ? 2 : (e > 16 ? 16 : e);
+  return y > 0.19264507f ? bits : 0;                        // two bits beat none iff lambda < 0.875 biasedSF
+}
+
+__global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
+  __shared__ double biased_s[64];
+  const C1DevEncOpts *O = L.opts;
+  if (threadIdx.x < 64) biased_s[threadIdx.x] = ((const __attribute__((address_space(4))) double *)O->biased)[threadIdx.x];
+  __syncthreads();
+  const float la_slope = O->la_slope, la_off = O->la_off;
+  const int lane = threadIdx.x & 63;
+  const uint32_t count = L.work_count[1];
+  for (uint32_t pos0 = blockIdx.x * 256u; pos0 < count; pos0 += gridDim.x * 256u) {
+    const uint32_t pos = pos0 + threadIdx.x;
+    const bool live = pos < count;
+    const int64_t unit = live ? (int64_t)L.sel_list[pos] : (int64_t)L.sel_list[0];
+    uint32_t sf[13];
+    load_sfi(L.side, unit, sf);
+    uint8_t *base = L.cand + unit * kCandBytes;
+    double *tot = reinterpret_cast<double *>(base);
+    double *lb = reinterpret_cast<double *>(base + kCandLbOffset);
+    const double best = tot[7];
+    // bracket of log2 lambda for the first candidate: from "every BFU at 16 bits" to "nothing coded"
+    int smin = 64, smax = 0;
+#pragma unroll
+    for (int b = 0; b < 52; b++) {
+      const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+      if (s != 0) { smin = s < smin ? s : smin; smax = s > smax ? s : smax; }
+    }
+    float x_prev = 0.0f;
+    bool have_prev = false;
+    int c_star = -1;
+    double lb_star = __builtin_huge_val();
+    for (int c = 0; c < 7; c++) {
+      const bool mine = live && tot[c] == kAlive;
+      if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
+      const int n = bfu_amount(c);
+      const int B = 212 * 8 - 40 - 10 * n;
+      float lo = have_prev ? x_prev - 0.05f : __builtin_fmaf(la_slope, (float)smin, la_off) - 17.0f;
+      float hi = have_prev ? x_prev + 3.15f : __builtin_fmaf(la_slope, (float)smax, la_off);
+      const int iters = __builtin_amdgcn_ballot_w64(mine && !have_prev) != 0 ? 10 : 6;
+      for (int it = 0; it < iters; it++) {
+        const float x = 0.5f * (lo + hi);
+        const float base_y = la_off - x;
+        int used = 0;
+#pragma unroll
+        for (int b = 0; b < 52; b++) {
+          if (b < n) {
+            const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+            const int bits = relaxed_bits(__builtin_fmaf(la_slope, (float)s, base_y));
+            used += s != 0 ? bits * (int)kSpecs[b] : 0;
+          }
+        }
+        if (used > B) lo = x; else hi = x;
+      }
+      const float x = hi;
+      const double lambda = (double)__builtin_amdgcn_exp2f(x);
+      const double inv_lambda = 1.0 / lambda;
+      double P = 0.0;
+#pragma unroll
+      for (int b = 0; b < 52; b++) {
+        const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+        const double a = biased_s[s], size = (double)kSpecs[b];
+        const double z = (double)f32(a * 2.0 * size);                 // zeroBitDistortions[b] (:87-89)
+        double g = z;
+        if (b < n) {
+          const double q = a * inv_lambda;
+          int e = ((__double2hiint(q) >> 20) & 0x7ff) - 1023;         // floor(log2 q) for normal q
+          e = e < 2 ? 2 : (e > 16 ? 16 : e);
+          const double ip2 = __hiloint2double((1023 - e) << 20, 0);
+          const double h = a * ip2 * size + lambda * size * (double)e;   // (:183-187) + the price of e bits
+          g = h < z ? h : z;
+        }
+        P += s != 0 ? g : 0.0;
+      }
+      const double M = lambda * (double)B;
+      const double bound = (P - M) - 5.684341886080802e-14 * (P + M);
+      if (mine) {
+        if (bound > best) tot[c] = __builtin_huge_val();               // cannot win, cannot tie
+        else {
+          lb[c] = bound;
+          if (bound < lb_star || c_star < 0) { lb_star = bound; c_star = c; }
+        }
+        x_prev = x; have_prev = true;
+      }
+    }
+    // first round of heaps: the candidate with the smallest bound
+    const bool has = live && c_star >= 0;
+    if (live) reinterpret_cast<int *>(lb + 7)[0] = c_star;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(has);
+    uint32_t at = 0;
+    if (lane == 0 && m != 0) at = atomicAdd(L.work_count, (uint32_t)__popcll(m));
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+    if (has) L.work_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)unit << 3) | (uint32_t)c_star;
+  }
+}
+
+// after the first round: what is still alive and not above the best total known goes to the second round
+__global__ __launch_bounds__(256) void k_alloc_pick2(C1EncodeLaunch L, uint32_t *list2) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t count = L.work_count[1];
+  for (uint32_t pos0 = blockIdx.x * 256u; pos0 < count; pos0 += gridDim.x * 256u) {
+    const uint32_t pos = pos0 + threadIdx.x;
+    const bool live = pos < count;
+    const int64_t unit = live ? (int64_t)L.sel_list[pos] : (int64_t)L.sel_list[0];
+    uint8_t *base = L.cand + unit * kCandBytes;
+    double *tot = reinterpret_cast<double *>(base);
+    const double *lb = reinterpret_cast<const double *>(base + kCandLbOffset);
+    double best = tot[7];
+    const int c_star = reinterpret_cast<const int *>(lb + 7)[0];
+    if (live && c_star >= 0) { const double t1 = tot[c_star]; best = t1 < best ? t1 : best; }
+    uint32_t keep = 0;
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 7; c++) {
+        if (tot[c] == kAlive) {
+          if (lb[c] > best) tot[c] = __builtin_huge_val();
+          else keep |= 1u << c;
+        }
+      }
+    }
+    const int mine = __popc(keep);
+    const int scan = wave_inclusive_scan(mine);
+    const int wave_total = __builtin_amdgcn_readlane(scan, 63);
+    uint32_t at = 0;
+    if (lane == 0 && wave_total > 0) at = atomicAdd(L.work_count + 2, (uint32_t)wave_total);
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)(scan - mine);
+    for (int c = 0; c < 7; c++)
+      if ((keep >> c) & 1u) list2[at++] = ((uint32_t)unit << 3) | (uint32_t)c;
+  }
+}
+
+__global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count) {
   __shared__ uint32_t heap[kHeapSlotsPerLane * 64];
   const C1DevEncOpts *O = L.opts;
   const int lane = threadIdx.x;
-  const uint32_t count = *L.work_count;
+  const uint32_t count = *list_count;
   for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
     const uint32_t idx = base + lane;
     const bool live = idx < count;
-    const uint32_t item = live ? L.work_list[idx] : 0u;
+    const uint32_t item = live ? list[idx] : 0u;
     const int64_t unit = item >> 3;
     const int c = item & 7;
     uint32_t sf[13];
@@ -312,11 +464,18 @@ __global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
   const bool listed = L.unit_list != nullptr;            // the list's length is only known on the device: bounded grids stride over it
-  (void)hipMemsetAsync(L.work_count, 0, 2 * sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(L.work_count, 0, 3 * sizeof(uint32_t), stream);
   const int64_t first_blocks = listed ? std::min<int64_t>((units + 63) / 64, 256 * 12) : (units + 63) / 64;
   hipLaunchKernelGGL(k_alloc_first, dim3((unsigned)first_blocks), dim3(C1_WAVE), 0, stream, L);
-  const int64_t rest_blocks = std::min<int64_t>((units * 7 + 63) / 64, 256 * 10);
-  hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest_blocks), dim3(C1_WAVE), 0, stream, L);
+  // every kernel below strides over a list whose length only the device knows
+  const int64_t unit_blocks = std::min<int64_t>((units + 255) / 256, 2048);
+  uint32_t *list2 = L.work_list + units;                   // first round: at most one entry per unit
+  hipLaunchKernelGGL(k_alloc_bound, dim3((unsigned)unit_blocks), dim3(256), 0, stream, L);
+  const int64_t rest1_blocks = std::min<int64_t>((units + 63) / 64, 256 * 10);
+  hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest1_blocks), dim3(C1_WAVE), 0, stream, L, (const uint32_t *)L.work_list, (const uint32_t *)L.work_count);
+  hipLaunchKernelGGL(k_alloc_pick2, dim3((unsigned)unit_blocks), dim3(256), 0, stream, L, list2);
+  const int64_t rest2_blocks = std::min<int64_t>((units * 6 + 63) / 64, 256 * 10);
+  hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest2_blocks), dim3(C1_WAVE), 0, stream, L, (const uint32_t *)list2, (const uint32_t *)(L.work_count + 2));
   const int64_t select_blocks = std::min<int64_t>((units + 255) / 256, 1024);      // strides over the selection list
   hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)select_blocks), dim3(256), 0, stream, L);
 }
