@@ -340,6 +340,7 @@ int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
   return C1_OK;
 }
 
+constexpr int64_t kSpecProbeFrames = 32768;            // adaptive speculation: frames speculated at the start of every 16th call of a stream in exact mode
 constexpr int64_t kMaxChunkFrames = (int64_t)1 << 27;   // x 2 channels = 2^28 units per chunk < 2^29
 
 struct Timing {
@@ -586,6 +587,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   const bool all_short_modes = !detect && opts->fixed_block_modes[0] != 0 && opts->fixed_block_modes[1] != 0 &&
                                opts->fixed_block_modes[2] != 0;
   bool speculate = (all_long_modes || all_short_modes) && !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;
+  int64_t probe_frames = 0;
   if (speculate && ctx->spec_mode == 1) {
     // adaptive: look at what the previous speculative call had to redo (its kernels have normally finished by now).
     // Signals whose spectrum is far from flat (tones) fail the guard band for most units; then the speculative pass
@@ -597,9 +599,15 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       if (du > 0) { ctx->spec_last_fraction = (double)dr / (double)du; ctx->spec_exact_calls = 0; }
       ctx->spec_seen[0] = tot[0]; ctx->spec_seen[1] = tot[1];
     }
-    if (ctx->spec_last_fraction > 0.30 && ctx->spec_exact_calls < 15) { speculate = false; ctx->spec_exact_calls++; }
+    if (ctx->spec_last_fraction > 0.30) {
+      // exact kernels for this call; every 16th call a slice at its start is speculated to see whether the material
+      // has changed (a whole speculative call on tonal material costs three times an exact one)
+      if (ctx->spec_exact_calls < 15) ctx->spec_exact_calls++;
+      else probe_frames = std::min<int64_t>(frames, kSpecProbeFrames);
+      speculate = false;
+    }
   }
-  const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate;
+  const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate && probe_frames == 0;
   hipStream_t sA = piped ? ctx->s_ana : ctx->stream, sB = piped ? ctx->s_rest : ctx->stream;
   if (piped) {
     HIP_TRY(hipEventRecord(ctx->ev_in, ctx->stream));
@@ -607,8 +615,9 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     HIP_TRY(hipStreamWaitEvent(sB, ctx->ev_in, 0));
   }
   int64_t index = 0;
-  for (int64_t f0 = 0; f0 < frames; f0 += taps ? frames : chunk, ++index) {
-    const int64_t n = taps ? frames : std::min(chunk, frames - f0);
+  for (int64_t f0 = 0, n = 0; f0 < frames; f0 += n, ++index) {
+    const bool probing = probe_frames > 0 && f0 == 0;
+    n = taps ? frames : (probing ? probe_frames : std::min(chunk, frames - f0));
     const int p = piped ? (int)(index & 1) : 0;
     C1EncodeLaunch L;
     memset(&L, 0, sizeof L);
@@ -629,7 +638,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     const bool all_long = all_long_modes;
     if (piped && index >= 2) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_free[p], 0));   // workspace half p is free again
-    if (speculate) {
+    if (speculate || probing) {
       // Speculative pass in binary32 (c1_k_spec.hip): coefficients with a proven error bound; allocation works on the
       // scale-factor indices; the packing kernel accepts a unit only when every decision is certain within the bound
       // and lists the others.  Then the exact kernels redo the listed units in place.

@@ -17,9 +17,9 @@ namespace {
 //   k_alloc_bound   one lane per unit that still has candidates alive: a second, much sharper lower bound for each of
 //                   them (Lagrangian relaxation of the greedy's knapsack, below), drops what that already excludes
 //                   and sends the most promising candidate of the unit to the first round of heaps.
-//   k_alloc_rest    one lane per work-list entry (unit, candidate): the same heap run.
-//   k_alloc_pick2   one lane per such unit: the candidates whose bound does not exceed the best total known now
-//                   (52 BFUs or the first-round result) go to the second round; the others can never win.
+//   k_alloc_rest    one lane per work-list entry (unit, candidate): the same heap run.  First round: one entry per
+//                   unit; the lane then sends the unit's other candidates whose bound does not exceed the best total
+//                   known now (52 BFUs or this one) to the second round; the others can never win.
 //   k_alloc_select  one lane per unit: smallest total, smallest count on ties (:116-129), or the
 //                   fallback when no total is finite (:132-139).
 // On white noise 97 % of the units stop after k_alloc_first; stationary tonal material keeps all eight candidates
@@ -279,6 +279,9 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
 // totals it is compared with.  A candidate is dropped only when this bound is strictly above a total that was really
 // computed, i.e. when it cannot even tie (:116-129 keeps the earlier candidate on ties).
 // =====================================================================================================
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+constexpr int kSpecsHost[52] = {8, 8, 8, 8, 4, 4, 4, 4, 8, 8, 8, 8, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 9, 9, 9, 9, 10, 10, 10, 10,
+                                12, 12, 12, 12, 12, 12, 12, 12, 20, 20, 20, 20, 20, 20, 20, 20};   // kSpecs as compile-time constants
 __device__ __forceinline__ int relaxed_bits(float y) {      // word length in bits the relaxed problem gives a BFU with log2(biasedSF / lambda) = y
   const int e = (int)__builtin_floorf(y);
   const int bits = e < 2 ? 2 : (e > 16 ? 16 : e);
@@ -288,7 +291,8 @@ __device__ __forceinline__ int relaxed_bits(float y) {      // word length in bi
 __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
   __shared__ double biased_s[64];
   const C1DevEncOpts *O = L.opts;
-  if (threadIdx.x < 64) biased_s[threadIdx.x] = ((const __attribute__((address_space(4))) double *)O->biased)[threadIdx.x];
+  // index 0 = silent BFU: with a zero here every term of such a BFU below is zero by itself
+  if (threadIdx.x < 64) biased_s[threadIdx.x] = threadIdx.x == 0 ? 0.0 : ((const __attribute__((address_space(4))) double *)O->biased)[threadIdx.x];
   __syncthreads();
   const float la_slope = O->la_slope, la_off = O->la_off;
   const int lane = threadIdx.x & 63;
@@ -310,6 +314,17 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
       const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
       if (s != 0) { smin = s < smin ? s : smin; smax = s > smax ? s : smax; }
     }
+    // The multiplier search needs no precision (every lambda gives a valid bound; a poor one only prunes less), so it
+    // runs on packed halves: two BFUs per instruction, the spend accumulated by v_dot2_f32_f16.  The relaxed word
+    // length floor(y) is replaced by its mean y - 1/2 (clamped to 2..16 bits, nothing below the point where two bits
+    // stop paying); silent BFUs sit far below everything.
+    h2 sp[26];
+#pragma unroll
+    for (int k = 0; k < 26; k++) {
+      const int s0 = (sf[(2 * k) >> 2] >> (((2 * k) & 3) * 8)) & 63, s1 = (sf[(2 * k + 1) >> 2] >> (((2 * k + 1) & 3) * 8)) & 63;
+      sp[k] = h2{s0 != 0 ? (_Float16)s0 : (_Float16)-1000.0f, s1 != 0 ? (_Float16)s1 : (_Float16)-1000.0f};
+    }
+    const h2 slope2 = h2{(_Float16)la_slope, (_Float16)la_slope};
     float x_prev = 0.0f;
     bool have_prev = false;
     int c_star = -1;
@@ -324,17 +339,20 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
       const int iters = __builtin_amdgcn_ballot_w64(mine && !have_prev) != 0 ? 10 : 6;
       for (int it = 0; it < iters; it++) {
         const float x = 0.5f * (lo + hi);
-        const float base_y = la_off - x;
-        int used = 0;
+        const _Float16 by = (_Float16)(la_off - x - 0.5f);
+        const h2 base2 = h2{by, by};
+        float used = 0.0f;
 #pragma unroll
-        for (int b = 0; b < 52; b++) {
-          if (b < n) {
-            const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
-            const int bits = relaxed_bits(__builtin_fmaf(la_slope, (float)s, base_y));
-            used += s != 0 ? bits * (int)kSpecs[b] : 0;
+        for (int k = 0; k < 26; k++) {
+          if (2 * k < n) {
+            const h2 y = __builtin_elementwise_fma(sp[k], slope2, base2);                     // log2(biasedSF / lambda) - 1/2
+            const h2 bits = __builtin_elementwise_min(__builtin_elementwise_max(y, h2{(_Float16)2.0f, (_Float16)2.0f}), h2{(_Float16)16.0f, (_Float16)16.0f});
+            const h2 ramp = __builtin_elementwise_fma(y, h2{(_Float16)64.0f, (_Float16)64.0f}, h2{(_Float16)20.0f, (_Float16)20.0f});   // 0 below y = -0.31, 1 above -0.30
+            const h2 on = __builtin_elementwise_min(__builtin_elementwise_max(ramp, h2{(_Float16)0.0f, (_Float16)0.0f}), h2{(_Float16)1.0f, (_Float16)1.0f});
+            used = __builtin_amdgcn_fdot2(bits * on, h2{(_Float16)(float)kSpecsHost[2 * k], (_Float16)(float)kSpecsHost[2 * k + 1]}, used, false);
           }
         }
-        if (used > B) lo = x; else hi = x;
+        if (used > (float)B) lo = x; else hi = x;
       }
       const float x = hi;
       const double lambda = (double)__builtin_amdgcn_exp2f(x);
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
           const double h = a * ip2 * size + lambda * size * (double)e;   // (:183-187) + the price of e bits
           g = h < z ? h : z;
         }
-        P += s != 0 ? g : 0.0;
+        P += g;
       }
       const double M = lambda * (double)B;
       const double bound = (P - M) - 5.684341886080802e-14 * (P + M);
@@ -378,42 +396,12 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
   }
 }
 
-// after the first round: what is still alive and not above the best total known goes to the second round
-__global__ __launch_bounds__(256) void k_alloc_pick2(C1EncodeLaunch L, uint32_t *list2) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t count = L.work_count[1];
-  for (uint32_t pos0 = blockIdx.x * 256u; pos0 < count; pos0 += gridDim.x * 256u) {
-    const uint32_t pos = pos0 + threadIdx.x;
-    const bool live = pos < count;
-    const int64_t unit = live ? (int64_t)L.sel_list[pos] : (int64_t)L.sel_list[0];
-    uint8_t *base = L.cand + unit * kCandBytes;
-    double *tot = reinterpret_cast<double *>(base);
-    const double *lb = reinterpret_cast<const double *>(base + kCandLbOffset);
-    double best = tot[7];
-    const int c_star = reinterpret_cast<const int *>(lb + 7)[0];
-    if (live && c_star >= 0) { const double t1 = tot[c_star]; best = t1 < best ? t1 : best; }
-    uint32_t keep = 0;
-    if (live) {
-#pragma unroll
-      for (int c = 0; c < 7; c++) {
-        if (tot[c] == kAlive) {
-          if (lb[c] > best) tot[c] = __builtin_huge_val();
-          else keep |= 1u << c;
-        }
-      }
-    }
-    const int mine = __popc(keep);
-    const int scan = wave_inclusive_scan(mine);
-    const int wave_total = __builtin_amdgcn_readlane(scan, 63);
-    uint32_t at = 0;
-    if (lane == 0 && wave_total > 0) at = atomicAdd(L.work_count + 2, (uint32_t)wave_total);
-    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)(scan - mine);
-    for (int c = 0; c < 7; c++)
-      if ((keep >> c) & 1u) list2[at++] = ((uint32_t)unit << 3) | (uint32_t)c;
-  }
-}
-
-__global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count) {
+// FIRST_ROUND: every entry is the most promising candidate of its unit (one entry per unit).  With its total known,
+// the unit's other live candidates are settled on the spot: a bound above the best total known now (52 BFUs or this
+// one) can never win, the rest is appended to the second round's list.
+template <bool FIRST_ROUND>
+__global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count,
+                                                           uint32_t *__restrict__ list2) {
   __shared__ uint32_t heap[kHeapSlotsPerLane * 64];
   const C1DevEncOpts *O = L.opts;
   const int lane = threadIdx.x;
@@ -429,7 +417,33 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L, con
     uint64_t r0, r1, r2, r3;
     double total;
     run_candidate(heap + lane, bfu_amount(c), sf, O, live, r0, r1, r2, r3, total);
-    if (live) store_candidate(L.cand, unit, c, total < __builtin_huge_val() ? total : __builtin_huge_val(), r0, r1, r2, r3);
+    total = total < __builtin_huge_val() ? total : __builtin_huge_val();
+    if (live) store_candidate(L.cand, unit, c, total, r0, r1, r2, r3);
+    if constexpr (FIRST_ROUND) {
+      uint8_t *cbase = L.cand + unit * kCandBytes;
+      double *tot = reinterpret_cast<double *>(cbase);
+      const double *lb = reinterpret_cast<const double *>(cbase + kCandLbOffset);
+      uint32_t keep = 0;
+      if (live) {
+        const double t52 = tot[7];
+        const double best = total < t52 ? total : t52;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          if (k != c && tot[k] == kAlive) {
+            if (lb[k] > best) tot[k] = __builtin_huge_val();
+            else keep |= 1u << k;
+          }
+        }
+      }
+      const int mine = __popc(keep);
+      const int scan = wave_inclusive_scan(mine);
+      const int wave_total = __builtin_amdgcn_readlane(scan, 63);
+      uint32_t at = 0;
+      if (lane == 0 && wave_total > 0) at = atomicAdd(L.work_count + 2, (uint32_t)wave_total);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)(scan - mine);
+      for (int k = 0; k < 7; k++)
+        if ((keep >> k) & 1u) list2[at++] = ((uint32_t)unit << 3) | (uint32_t)k;
+    }
   }
 }
 
@@ -472,10 +486,9 @@ void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {
   uint32_t *list2 = L.work_list + units;                   // first round: at most one entry per unit
   hipLaunchKernelGGL(k_alloc_bound, dim3((unsigned)unit_blocks), dim3(256), 0, stream, L);
   const int64_t rest1_blocks = std::min<int64_t>((units + 63) / 64, 256 * 10);
-  hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest1_blocks), dim3(C1_WAVE), 0, stream, L, (const uint32_t *)L.work_list, (const uint32_t *)L.work_count);
-  hipLaunchKernelGGL(k_alloc_pick2, dim3((unsigned)unit_blocks), dim3(256), 0, stream, L, list2);
+  hipLaunchKernelGGL((k_alloc_rest<true>), dim3((unsigned)rest1_blocks), dim3(C1_WAVE), 0, stream, L, (const uint32_t *)L.work_list, (const uint32_t *)L.work_count, list2);
   const int64_t rest2_blocks = std::min<int64_t>((units * 6 + 63) / 64, 256 * 10);
-  hipLaunchKernelGGL(k_alloc_rest, dim3((unsigned)rest2_blocks), dim3(C1_WAVE), 0, stream, L, (const uint32_t *)list2, (const uint32_t *)(L.work_count + 2));
+  hipLaunchKernelGGL((k_alloc_rest<false>), dim3((unsigned)rest2_blocks), dim3(C1_WAVE), 0, stream, L, (const uint32_t *)list2, (const uint32_t *)(L.work_count + 2), (uint32_t *)nullptr);
   const int64_t select_blocks = std::min<int64_t>((units + 255) / 256, 1024);      // strides over the selection list
   hipLaunchKernelGGL(k_alloc_select, dim3((unsigned)select_blocks), dim3(256), 0, stream, L);
 }

@@ -43,11 +43,14 @@ __device__ __forceinline__ void wave_sync() {
 constexpr int kPackWaves = 4;            // independent waves per workgroup, one sound unit at a time each
 constexpr int kPackBlocks = 2048;        // persistent grid: waves stride over the units
 
+constexpr int kRedoBatch = 32;           // one atomic on the list's counter per 32 listed units of a wave (every listed unit paying
+                                         // its own serialises the whole kernel on that one address when most units are listed)
 struct PackLds {
   uint32_t words[56];         // the unit as big-endian 32-bit groups
   uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
   double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
   float2 ng[52];              // speculative path: (fl32 of the same, guard band eps_band * norm (1 + 2^-20) + 2^-22 of the BFU)
+  uint32_t redo[kRedoBatch];  // speculative path: units to redo, appended to the global list a batch at a time
 };
 
 // One wave per sound unit.  A lane owns 8 consecutive coefficient slots (BFU-major order == bitstream
@@ -137,6 +140,14 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
   PackHeader h1 = pack_load_header<SPEC>(L, unit_at(u_first + stride < units_total ? u_first + stride : u_first), lane);
   float x[8];
   load_coefs(unit_at(u_first), __shfl(h0.sd_q, 13), x);
+  int n_redo = 0;                          // wave-uniform: entries waiting in S.redo
+  auto flush_redo = [&]() {
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(L.redo_count, (uint32_t)n_redo);
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+    if (lane < n_redo) L.redo_list[at + lane] = S.redo[lane];
+    n_redo = 0;
+  };
   for (int64_t pos = u_first; pos < units_total; pos += stride) {
     const int64_t unit = unit_at(pos);
     // ---- issue the loads of the units ahead ----
@@ -271,13 +282,18 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     if constexpr (SPEC) {
       // flag word of the analysis (a scale-factor index was not certain) or any doubtful mantissa -> exact redo
       const bool redo = __builtin_amdgcn_ballot_w64(doubtful) != 0 || __float_as_int(__shfl(h0.eps, 3)) != 0;
-      if (redo && lane == 0) L.redo_list[atomicAdd(L.redo_count, 1u)] = (uint32_t)unit;
+      if (redo) {
+        if (lane == 0) S.redo[n_redo] = (uint32_t)unit;
+        n_redo++;
+      }
     }
     wave_sync();
+    if constexpr (SPEC) { if (n_redo == kRedoBatch) flush_redo(); }
     h0 = h1; h1 = h2;
 #pragma unroll
     for (int m = 0; m < 8; m++) x[m] = xn[m];
   }
+  if constexpr (SPEC) { if (n_redo > 0) flush_redo(); }
 }
 
 }  // namespace

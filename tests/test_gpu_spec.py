@@ -119,6 +119,29 @@ def test_adaptive_mode_sends_tonal_streams_to_the_exact_kernels(ctx):
     ctx.set_speculation(1)
 
 
+def test_adaptive_mode_probes_a_slice_every_16th_call(ctx):
+    """a stream in exact mode speculates only the first 32 768 frames of every 16th call; the units never change"""
+    import carta1_amd as c1
+    frames = 40000
+    t = np.arange(frames * 512)
+    tone = (0.4 * np.sin(2 * np.pi * 440 * t / 44100) + 0.1 * np.sin(2 * np.pi * 3520 * t / 44100)).astype(np.float32)
+    opts = c1.EncoderOptions(LONG)
+    ctx.set_speculation(0)
+    exact = ctx.encode([tone], opts).copy()
+    ctx.set_speculation(1)
+    ctx.speculation_stats(reset=True)
+    assert np.array_equal(ctx.encode([tone], opts), exact)       # first call of the stream: speculated as a whole
+    u1, r1 = ctx.speculation_stats()
+    assert u1 == frames and r1 > 0.5 * u1
+    for _ in range(15):
+        assert np.array_equal(ctx.encode([tone], opts), exact)   # exact kernels: the totals stand still
+    assert ctx.speculation_stats() == (u1, r1)
+    assert np.array_equal(ctx.encode([tone], opts), exact)       # the 17th call probes a slice
+    u2, r2 = ctx.speculation_stats()
+    assert u2 == u1 + 32768 and r2 > r1
+    ctx.set_speculation(1)
+
+
 def test_halo_and_unaligned_runs(ctx):
     """slices of a stream with their halo frames, lengths that are not multiples of the 64-frame run"""
     import carta1_amd as c1
