@@ -84,6 +84,7 @@ SIGNATURES = {
     'c1_detect_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                           C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p]),
     'c1_libm_device': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
+    'c1_alloc_bounds_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'c1_spec_stages_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                         C.POINTER(EncodeOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
 }

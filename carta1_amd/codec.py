@@ -225,6 +225,11 @@ class Context:
         """Math.log / exp / log1p / log10 (fn 0..3) as the detector's kernels evaluate them, on n device doubles."""
         capi.check(capi.load().c1_libm_device(self._h, fn, C.c_void_p(in_ptr), C.c_void_p(out_ptr), n))
 
+    def alloc_bounds_device(self, side_ptr, units, out_ptr, options=None):
+        """Totals of the eight candidate BFU counts and the lower bounds the allocation prunes with (16 doubles per unit)."""
+        opts = (options or EncoderOptions()).to_c()
+        capi.check(capi.load().c1_alloc_bounds_device(self._h, C.c_void_p(side_ptr), units, C.byref(opts), C.c_void_p(out_ptr)))
+
     def spec_stages_device(self, pcm_ptrs, frames, coefs_ptr, eps_ptr, side_ptr, options=None, halo_frames=0):
         """The speculative binary32 analysis alone: coefficients, their proven error bounds, scale-factor indices."""
         opts = (options or EncoderOptions({'fixedBlockModes': [0, 0, 0]})).to_c()

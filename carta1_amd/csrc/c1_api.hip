@@ -985,6 +985,31 @@ int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   return C1_OK;
 }
 
+int c1_alloc_bounds_device(c1_ctx *ctx, const uint8_t *side, int64_t units, const c1_encode_options *opts, double *out) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (units < 0 || units > ((int64_t)1 << 24) || (units > 0 && (!side || !out))) return fail(C1_ERR_ARG, "bad units / NULL argument");
+  if ((rc = upload_opts(ctx, opts))) return rc;
+  if (units == 0) return C1_OK;
+  if ((rc = ensure_workspace(ctx, units * 2))) return rc;        // the tap lists all eight candidates of every unit: 9 list entries per unit
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  L.channels = 1;
+  L.frames = units;
+  L.tables = ctx->d_tables;
+  L.opts = ctx->d_opts;
+  L.side = const_cast<uint8_t *>(side);
+  L.alloc = ctx->d_alloc[0];
+  L.cand = ctx->d_cand[0];
+  L.work_count = ctx->d_work[0];
+  L.work_list = ctx->d_work[0] + 4;
+  L.sel_list = ctx->d_work[0] + 4 + (size_t)ctx->ws_units * 7;
+  c1k_launch_alloc_tap(L, out, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
 int c1_libm_device(c1_ctx *ctx, int fn, const double *in, double *out, int64_t n) {
   CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);

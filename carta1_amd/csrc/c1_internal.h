@@ -148,6 +148,7 @@ void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws
                        hipStream_t stream);
 void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream);
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
+void c1k_launch_alloc_tap(const C1EncodeLaunch &L, double *out, hipStream_t stream);   // test tap: totals and lower bounds of all candidates
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
 void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream);

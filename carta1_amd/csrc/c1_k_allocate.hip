@@ -473,6 +473,45 @@ __global__ __launch_bounds__(256) void k_alloc_select(C1EncodeLaunch L) {
   }
 }
 
+// ---- test tap: every candidate's total next to its lower bound (c1_alloc_bounds_device) -------------------------------
+__global__ __launch_bounds__(256) void k_alloc_tap_init(C1EncodeLaunch L, int64_t units) {
+  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (unit == 0) { L.work_count[0] = 0; L.work_count[1] = (uint32_t)units; L.work_count[2] = (uint32_t)(units * 8); }
+  if (unit >= units) return;
+  double *tot = reinterpret_cast<double *>(L.cand + unit * kCandBytes);
+  for (int c = 0; c < 7; c++) tot[c] = kAlive;            // everything alive, nothing known: the bound kernel drops nothing
+  tot[7] = __builtin_huge_val();
+  L.sel_list[unit] = (uint32_t)unit;
+  for (int c = 0; c < 8; c++) L.work_list[units + unit * 8 + c] = ((uint32_t)unit << 3) | (uint32_t)c;
+}
+__global__ __launch_bounds__(256) void k_alloc_tap_gather(C1EncodeLaunch L, int64_t units, double *out) {
+  const int64_t unit = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (unit >= units) return;
+  const double *tot = reinterpret_cast<const double *>(L.cand + unit * kCandBytes);
+  const double *lb = reinterpret_cast<const double *>(L.cand + unit * kCandBytes + kCandLbOffset);
+  for (int c = 0; c < 8; c++) { out[unit * 16 + c] = tot[c]; out[unit * 16 + 8 + c] = c < 7 ? lb[c] : 0.0; }
+  // slot 15: what the production path (c1k_launch_allocate, run before the tap) chose: amount index, or -1 for the fallback
+  const uint32_t a7 = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes)[7];
+  out[unit * 16 + 15] = ((a7 >> 27) & 1u) ? -1.0 : (double)((a7 >> 28) & 7u);
+}
+
+}  // namespace
+
+// out: units x 16 doubles: totals of the eight candidates (calculateTotalDistortion after distributeBitsRDO), then the
+// seven lower bounds k_alloc_bound gives them, then the candidate the production path chose.  Needs a work list of
+// 9 entries per unit.
+void c1k_launch_alloc_tap(const C1EncodeLaunch &L, double *out, hipStream_t stream) {
+  const int64_t units = L.frames * L.channels;
+  c1k_launch_allocate(L, stream);                           // the pruned path, for slot 15
+  const dim3 grid((unsigned)((units + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_alloc_tap_init, grid, block, 0, stream, L, units);
+  hipLaunchKernelGGL(k_alloc_bound, dim3((unsigned)std::min<int64_t>((units + 255) / 256, 2048)), block, 0, stream, L);
+  hipLaunchKernelGGL((k_alloc_rest<false>), dim3((unsigned)std::min<int64_t>((units * 8 + 63) / 64, 256 * 10)), dim3(C1_WAVE), 0, stream, L,
+                     (const uint32_t *)(L.work_list + units), (const uint32_t *)(L.work_count + 2), (uint32_t *)nullptr);
+  hipLaunchKernelGGL(k_alloc_tap_gather, grid, block, 0, stream, L, units, out);
+}
+
+namespace {
 }  // namespace
 
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream) {

@@ -231,6 +231,14 @@ int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
  * rounded, so the algorithm itself is part of the parity contract).  in, out: n doubles, device pointers. */
 int c1_libm_device(c1_ctx *ctx, int fn, const double *in, double *out, int64_t n);
 
+/* Test tap of the bit allocation (allocateBits, bitallocation.js:74-142).  The library runs the greedy heap only for the
+ * candidate BFU counts that a lower bound on their total distortion does not exclude; this call shows both sides of
+ * that comparison.  side: units*64 bytes as above (sfi[52] of every unit); out: units*16 doubles = the totals of the
+ * eight candidates {20,28,32,36,40,44,48,52} as calculateTotalDistortion returns them (:157-190), then the seven lower
+ * bounds, then (slot 15) the index of the candidate the pruned production path chose, -1 for the fallback.  Device
+ * pointers.  tests/test_gpu_alloc_bound.py checks bound <= total everywhere and choice == brute-force minimum. */
+int c1_alloc_bounds_device(c1_ctx *ctx, const uint8_t *side, int64_t units, const c1_encode_options *opts, double *out);
+
 /* The speculative binary32 analysis on its own (diagnostics; tests/test_gpu_spec.py checks the bound with it):
  * coefs: frames*channels*512 floats = the binary32 coefficients; eps: frames*channels*4 floats = the proven bound on
  * |coefficient - reference coefficient| for bands 0, 1, 2 and a flag word (non-zero bit pattern: a scale-factor
