@@ -90,7 +90,7 @@ __device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, 
 // with any doubtful mantissa, or whose scale-factor indices were doubtful, goes to the redo list and is encoded
 // again by the exact kernels.
 template <bool ALL_LONG, bool SPEC>
-__global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack(C1EncodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) void k_pack(C1EncodeLaunch L) {
   __shared__ PackLds lds[kPackWaves];
   __shared__ typename std::conditional<SPEC, float, double>::type norm_s[64 * 16];   // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
   TablesPtr T = C1_TABLES(L.tables);
@@ -136,10 +136,6 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     }
   };
   if (u_first >= units_total) return;
-  PackHeader h0 = pack_load_header<SPEC>(L, unit_at(u_first), lane);
-  PackHeader h1 = pack_load_header<SPEC>(L, unit_at(u_first + stride < units_total ? u_first + stride : u_first), lane);
-  float x[8];
-  load_coefs(unit_at(u_first), __shfl(h0.sd_q, 13), x);
   int n_redo = 0;                          // wave-uniform: entries waiting in S.redo
   auto flush_redo = [&]() {
     uint32_t at = 0;
@@ -148,13 +144,25 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     if (lane < n_redo) L.redo_list[at + lane] = S.redo[lane];
     n_redo = 0;
   };
-  for (int64_t pos = u_first; pos < units_total; pos += stride) {
+  // Two register sets (header + coefficients) alternate between "the unit being packed" and "the unit in flight": the
+  // loop body exists twice with the sets swapped, so nothing is copied from one iteration to the next (the
+  // h0 = h1, h1 = h2, x = xn rotation of a three-deep pipeline was 22 of the kernel's 310 vector instructions per unit).
+  // The block modes a mixed-mode batch needs to address the next unit's coefficients are fetched one unit earlier.
+  auto modes_of = [&](int64_t pos) -> uint32_t {
+    if constexpr (ALL_LONG) return 0u;
+    else return reinterpret_cast<const uint32_t *>(L.side + unit_at(pos) * kSideBytes)[13];
+  };
+  PackHeader hA = pack_load_header<SPEC>(L, unit_at(u_first), lane), hB;
+  float xA[8], xB[8];
+  load_coefs(unit_at(u_first), modes_of(u_first), xA);
+  uint32_t modes_next = modes_of(u_first + stride < units_total ? u_first + stride : u_first);
+  auto step = [&](const PackHeader &h0, const float (&x)[8], PackHeader &hn, float (&xn)[8], int64_t pos) {
     const int64_t unit = unit_at(pos);
-    // ---- issue the loads of the units ahead ----
+    // ---- issue the loads of the unit ahead ----
     const int64_t u1 = pos + stride, u2 = pos + 2 * stride;
-    PackHeader h2 = pack_load_header<SPEC>(L, unit_at(u2 < units_total ? u2 : pos), lane);
-    float xn[8];
-    load_coefs(unit_at(u1 < units_total ? u1 : pos), __shfl(h1.sd_q, 13), xn);
+    hn = pack_load_header<SPEC>(L, unit_at(u1 < units_total ? u1 : pos), lane);
+    load_coefs(unit_at(u1 < units_total ? u1 : pos), modes_next, xn);
+    modes_next = modes_of(u2 < units_total ? u2 : pos);
     // ---- this unit ----
     const uint32_t a7 = h0.al7;
     const bool fallback = (a7 >> 27) & 1;
@@ -289,9 +297,10 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack
     }
     wave_sync();
     if constexpr (SPEC) { if (n_redo == kRedoBatch) flush_redo(); }
-    h0 = h1; h1 = h2;
-#pragma unroll
-    for (int m = 0; m < 8; m++) x[m] = xn[m];
+  };
+  for (int64_t pos = u_first; pos < units_total; pos += 2 * stride) {
+    step(hA, xA, hB, xB, pos);
+    if (pos + stride < units_total) step(hB, xB, hA, xA, pos + stride);
   }
   if constexpr (SPEC) { if (n_redo > 0) flush_redo(); }
 }
