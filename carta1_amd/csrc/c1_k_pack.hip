@@ -45,11 +45,13 @@ constexpr int kPackBlocks = 2048;        // persistent grid: waves stride over t
 
 constexpr int kRedoBatch = 32;           // one atomic on the list's counter per 32 listed units of a wave (every listed unit paying
                                          // its own serialises the whole kernel on that one address when most units are listed)
-struct PackLds {
+struct alignas(16) PackLds {
   uint32_t words[56];         // the unit as big-endian 32-bit groups
   uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
   double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
-  float2 ng[52];              // speculative path: (fl32 of the same, guard band eps_band * norm (1 + 2^-20) + 2^-22 of the BFU)
+  // speculative path, one 16-byte record per BFU (one ds_read_b128 per mantissa): bits | offset << 5, fl32(norm), the guard
+  // band eps_band * norm (1 + 2^-20) + 2^-22, the quantizer's range 2^(bits-1) - 1
+  alignas(16) uint4 rec[52];
   uint32_t redo[kRedoBatch];  // speculative path: units to redo, appended to the global list a batch at a time
 };
 
@@ -184,11 +186,11 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
     if (lane < 52) {
       const int mode = lane >= 36 ? m2 : (lane >= 20 ? m1 : m0);
       if constexpr (SPEC) {
-        // all-long: the third field is the quantizer's range 2^(bits-1) - 1 instead of a coefficient position
-        S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)((1 << (bits_b > 0 ? bits_b - 1 : 0)) - 1) << 16);
         const float nf = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0f;
         const float g = eb * nf;
-        S.ng[lane] = make_float2(nf, __builtin_fmaf(g, 9.5367431640625e-07f, g) + 2.384185791015625e-07f);
+        S.rec[lane] = make_uint4((uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5), __float_as_uint(nf),
+                                 __float_as_uint(__builtin_fmaf(g, 9.5367431640625e-07f, g) + 2.384185791015625e-07f),
+                                 (uint32_t)((1 << (bits_b > 0 ? bits_b - 1 : 0)) - 1));
       } else {
         S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
         S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
@@ -219,29 +221,32 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
       // LDS operations, groups shared with a neighbour need the OR anyway).
       // Quantization: |x| * norm + 0.5 in one fused operation; the reference's value of it lies within
       // et = guard + 2^-22 a of a, so the truncation is certain when fract(a) is in (et, 1 - et).
-      const uint32_t d0 = S.desc[slot_b[0]];
+      // The sign rides on the conversion (trunc(copysign(a, x)) = sign(x) trunc(a)), the clamp is one median of three.
+      // Guard: the truncation is certain when et < fract(a) < 1 - et, i.e. |fract(a) - 1/2| + et < 1/2; the two
+      // roundings of that sum are worth 2^-24 at most, the comparison below gives away 2^-23.
+      const uint32_t d0 = S.rec[slot_b[0]].x;
       const int pos0 = (int)((d0 >> 5) & 0x7ff) + slot_j[0] * (int)(d0 & 31);
       int cnt = pos0 & 31, wi = pos0 >> 5;
       uint64_t acc = 0;
-      float worst = 1.0f;
+      float worst = 0.0f;                                        // largest |fract - 1/2| + et of the lane
 #pragma unroll
       for (int p = 0; p < 4; p++) {
+        float tt[2];
 #pragma unroll
         for (int m = 2 * p; m < 2 * p + 2; m++) {
-          const uint32_t dsc = S.desc[slot_b[m]];
-          const float2 ng = S.ng[slot_b[m]];
-          const int bits = dsc & 31, range = (int)(dsc >> 16);
-          const float a = __builtin_fmaf(fabsf(x[m]), ng.x, 0.5f);
-          const int32_t q = (int32_t)a;                           // truncation; a >= 0
+          const uint4 r = S.rec[slot_b[m]];
+          const int bits = r.x & 31, range = (int)r.w;
+          const float a = __builtin_fmaf(fabsf(x[m]), __uint_as_float(r.y), 0.5f);
           const float d = __builtin_amdgcn_fractf(a);
-          const float et = __builtin_fmaf(a, 2.384185791015625e-07f, ng.y);
-          worst = fminf(worst, fminf(d - et, (1.0f - et) - d));
-          const int32_t qc = q > range ? range : q;
-          const int32_t sg = __float_as_int(x[m]) >> 31;          // all ones for negative x
-          const uint32_t v = (uint32_t)((qc ^ sg) - sg) & (uint32_t)(2 * range + 1);
+          const float et = __builtin_fmaf(a, 2.384185791015625e-07f, __uint_as_float(r.z));
+          tt[m - 2 * p] = fabsf(d - 0.5f) + et;
+          const int32_t q = (int32_t)__builtin_copysignf(a, x[m]);     // truncation towards zero
+          const int32_t qc = q < -range ? -range : (q > range ? range : q);   // v_med3_i32
+          const uint32_t v = (uint32_t)qc & (uint32_t)(2 * range + 1);
           acc = (acc << bits) | v;
           cnt += bits;
         }
+        worst = fmaxf(worst, fmaxf(tt[0], tt[1]));
         const bool full = cnt >= 32;
         const uint32_t w = full ? (uint32_t)(acc >> ((cnt - 32) & 31)) : 0u;
         atomicOr(&S.words[wi], w);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
         wi += full ? 1 : 0;
       }
       atomicOr(&S.words[wi], (uint32_t)(acc << ((32 - cnt) & 63)));   // the low cnt bits are the unwritten ones (cnt = 0: nothing)
-      doubtful = !(worst > 0.0f);
+      doubtful = !(worst < 0.49999988f);                          // 1/2 - 2^-23 (non-finite data: the analysis has flagged the unit)
     } else {
     uint64_t acc = 0;
     int cnt = -1, wi = 0;
