@@ -294,6 +294,8 @@ int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
     const double slope = (l63 - l1) / 62.0;
     d->la_slope = (std::isfinite(slope) && std::isfinite(l1)) ? (float)slope : 0.0f;
     d->la_off = (std::isfinite(slope) && std::isfinite(l1)) ? (float)(l1 - slope) : 0.0f;
+    static const int no_tonal = getenv("C1_ALLOC_NO_TONAL") ? atoi(getenv("C1_ALLOC_NO_TONAL")) : 0;
+    d->alloc_no_tonal = no_tonal;                        // experiments: 1 = always run the 52-BFU candidate first
   }
   float pri[64 * 15];
   std::vector<float> uniq;

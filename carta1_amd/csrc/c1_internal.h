@@ -65,7 +65,7 @@ struct C1DevEncOpts {
   // log2(biased[s]) ~ la_slope * s + la_off: only steers the multiplier search of the candidate bounds (k_alloc_bound);
   // the bounds themselves are formed from `biased`, so an inexact fit costs pruning power, never correctness
   float la_slope, la_off;
-  int32_t pad2_;
+  int32_t alloc_no_tonal;     // experiments (C1_ALLOC_NO_TONAL=1): always run the 52-BFU candidate first
 };
 
 // ---- geometry ------------------------------------------------------------------------------------

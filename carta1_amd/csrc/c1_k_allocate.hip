@@ -197,6 +197,8 @@ __device__ __forceinline__ void store_candidate(uint8_t *cand, int64_t unit, int
   dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
 }
 
+__device__ __forceinline__ bool getenv_no_tonal(const C1DevEncOpts *O) { return O->alloc_no_tonal != 0; }   // C1_ALLOC_NO_TONAL=1 (experiments)
+
 __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
   __shared__ uint32_t heap[kHeapSlotsPerLane * 64];
   const C1DevEncOpts *O = L.opts;
@@ -211,9 +213,41 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
   const int64_t unit = listed ? (int64_t)L.unit_list[live ? pos : 0] : pos;
   uint32_t sf[13];
   load_sfi(L.side, live ? unit : 0, sf);
+  // Which candidate to run first?  Where the upper BFUs carry next to nothing (tones, low-passed material) dropping
+  // them is free, a smaller candidate wins, and the 52-BFU heap would be run for nothing: such units go to
+  // k_alloc_bound with all eight candidates open.  The test is a guess (it only chooses the order of work, every
+  // path ends in the same exact comparison): the continuous relaxation of the 52-BFU problem spends its 1 136 bits at
+  // log2 lambda = (sum size_b log2 biasedSF_b - 1136) / N over the N coefficients of non-silent BFUs and then has a
+  // total of about N lambda / ln 2 (measured: the 52-BFU total is 0.7-1.0 of that estimate).  Units whose 52-BFU
+  // candidate wins have a zero-bit distortion t6 of the top four BFUs above 0.44 of the estimate (5 % quantile over
+  // white, pink and mixed material), units where a smaller candidate wins mostly below 0.4 (tools/alloc_tonal_stats.py).
+  bool tonal = false;
+  {
+    float n_coef = 0.0f, s_la = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 52; b++) {
+      const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+      const float w = s != 0 ? (float)kSpecs[b] : 0.0f;
+      n_coef += w;
+      s_la = __builtin_fmaf(w, (float)s, s_la);
+    }
+    // sum size la = la_slope * sum size s + la_off * N
+    const float la_sum = __builtin_fmaf(O->la_slope, s_la, O->la_off * n_coef);
+    const float t_est = 1.442695f * n_coef * __builtin_amdgcn_exp2f((la_sum - 1136.0f) / n_coef);
+    float t6f = 0.0f;                                       // zero-bit distortion of the top four BFUs (a guess needs no more than binary32)
+#pragma unroll
+    for (int b = 48; b < 52; b++) {
+      const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
+      t6f += s != 0 ? (float)biased[s] * (2.0f * (float)kSpecs[b]) : 0.0f;
+    }
+    const bool mine = n_coef > 0.0f && t6f < 0.35f * t_est && !getenv_no_tonal(O);
+    // one decision per wave (the majority's): a heap loop runs as long as any lane of the wave needs it, so skipping
+    // it pays only when every lane does
+    tonal = 2 * __popcll(__builtin_amdgcn_ballot_w64(live && mine)) > __popcll(__builtin_amdgcn_ballot_w64(live));
+  }
   uint64_t r0, r1, r2, r3;
   double total;
-  run_candidate(heap + lane, 52, sf, O, live, r0, r1, r2, r3, total);
+  run_candidate(heap + lane, 52, sf, O, live && !tonal, r0, r1, r2, r3, total);
   // lower bounds of the other seven candidates: zero-bit distortion of the BFUs they do not code, each
   // summed from its first uncoded BFU upwards (one pass, seven running sums)
   uint32_t survivors = 0;
@@ -238,6 +272,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
                 (!(finite && t4 > total) ? 16u : 0u) | (!(finite && t5 > total) ? 32u : 0u) |
                 (!(finite && t6 > total) ? 64u : 0u);
   }
+  if (tonal) survivors = 0xffu;                               // nothing evaluated, everything open (bit 7 = the 52-BFU candidate)
   const bool finite52 = total < __builtin_huge_val();
   if (live && survivors == 0) {
     // nothing else can win: the 52-BFU candidate is the allocation (or the fallback when its total is not finite,
@@ -251,7 +286,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
     double *tot = reinterpret_cast<double *>(base);
 #pragma unroll
     for (int c = 0; c < 7; c++) tot[c] = ((survivors >> c) & 1u) ? kAlive : __builtin_huge_val();
-    store_candidate(L.cand, unit, 7, finite52 ? total : __builtin_huge_val(), r0, r1, r2, r3);
+    if (tonal) tot[7] = kAlive;
+    else store_candidate(L.cand, unit, 7, finite52 ? total : __builtin_huge_val(), r0, r1, r2, r3);
   }
   // append the unit to the selection list: one atomic per wave
   const uint64_t sel_mask = __builtin_amdgcn_ballot_w64(live && survivors != 0);
@@ -309,7 +345,8 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
     uint8_t *base = L.cand + unit * kCandBytes;
     double *tot = reinterpret_cast<double *>(base);
     double *lb = reinterpret_cast<double *>(base + kCandLbOffset);
-    const double best = tot[7];
+    const double t52 = tot[7];
+    const double best = t52 == kAlive ? __builtin_huge_val() : t52;     // the 52-BFU candidate may be open too (k_alloc_first)
     // bracket of log2 lambda for the first candidate: from "every BFU at 16 bits" to "nothing coded"
     int smin = 64, smax = 0;
 #pragma unroll
@@ -332,7 +369,7 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
     bool have_prev = false;
     int c_star = -1;
     double lb_star = __builtin_huge_val();
-    for (int c = 0; c < 7; c++) {
+    for (int c = 0; c < 8; c++) {
       const bool mine = live && tot[c] == kAlive;
       if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
       const int n = bfu_amount(c);
@@ -390,7 +427,6 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
     }
     // first round of heaps: the candidate with the smallest bound
     const bool has = live && c_star >= 0;
-    if (live) reinterpret_cast<int *>(lb + 7)[0] = c_star;
     const uint64_t m = __builtin_amdgcn_ballot_w64(has);
     uint32_t at = 0;
     if (lane == 0 && m != 0) at = atomicAdd(L.work_count, (uint32_t)__popcll(m));
@@ -429,9 +465,9 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L, con
       uint32_t keep = 0;
       if (live) {
         const double t52 = tot[7];
-        const double best = total < t52 ? total : t52;
+        const double best = (c == 7 || t52 == kAlive || total < t52) ? total : t52;
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
+        for (int k = 0; k < 8; k++) {
           if (k != c && tot[k] == kAlive) {
             if (lb[k] > best) tot[k] = __builtin_huge_val();
             else keep |= 1u << k;
@@ -444,7 +480,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_rest(C1EncodeLaunch L, con
       uint32_t at = 0;
       if (lane == 0 && wave_total > 0) at = atomicAdd(L.work_count + 2, (uint32_t)wave_total);
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)(scan - mine);
-      for (int k = 0; k < 7; k++)
+      for (int k = 0; k < 8; k++)
         if ((keep >> k) & 1u) list2[at++] = ((uint32_t)unit << 3) | (uint32_t)k;
     }
   }
@@ -492,7 +528,7 @@ __global__ __launch_bounds__(256) void k_alloc_tap_gather(C1EncodeLaunch L, int6
   if (unit >= units) return;
   const double *tot = reinterpret_cast<const double *>(L.cand + unit * kCandBytes);
   const double *lb = reinterpret_cast<const double *>(L.cand + unit * kCandBytes + kCandLbOffset);
-  for (int c = 0; c < 8; c++) { out[unit * 16 + c] = tot[c]; out[unit * 16 + 8 + c] = c < 7 ? lb[c] : 0.0; }
+  for (int c = 0; c < 8; c++) { out[unit * 16 + c] = tot[c]; out[unit * 16 + 8 + c] = c < 7 ? lb[c] : 0.0; }   // (slot 15 is overwritten below)
   // slot 15: what the production path (c1k_launch_allocate, run before the tap) chose: amount index, or -1 for the fallback
   const uint32_t a7 = reinterpret_cast<const uint32_t *>(L.alloc + unit * kAllocBytes)[7];
   out[unit * 16 + 15] = ((a7 >> 27) & 1u) ? -1.0 : (double)((a7 >> 28) & 7u);
