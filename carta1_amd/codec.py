@@ -124,6 +124,12 @@ class Context:
         return u.value, r.value
 
     # ---- host-resident batches ------------------------------------------------------------------
+    def quantization_stats(self):
+        """(units whose exact coefficients were quantized in binary32 with the guard band, units packed again in binary64)"""
+        u, r = C.c_uint64(0), C.c_uint64(0)
+        capi.check(capi.load().c1_ctx_quantization_stats(self._h, C.byref(u), C.byref(r)))
+        return int(u.value), int(r.value)
+
     def encode(self, channels, options=None, halo_frames=0, out=None):
         """channels: list of 1 or 2 float32 arrays, each (halo_frames + frames) * 512 samples.
         Returns uint8 [frames * nch, 212], units interleaved L,R.  `out`: optional preallocated result (when it

@@ -383,6 +383,10 @@ struct c1_ctx {
   double spec_last_fraction = 0.0;               // redo fraction seen by the previous speculative call (adaptive mode)
   int spec_exact_calls = 0;                      // calls sent down the exact path since that observation
   unsigned long long spec_seen[2] = {0, 0};      // totals at the last observation
+  // binary32 quantization of exact coefficients (the exact paths' packing): the same bookkeeping, d_spec_totals[2..3]
+  double q32_last_fraction = 0.0;
+  int q32_off_calls = 0;
+  unsigned long long q32_seen[2] = {0, 0};
   // transient-detection workspace (allocated on first use): band samples, feature sums, block modes
   int64_t det_units = 0;
   float *d_bands[2] = {nullptr, nullptr};
@@ -589,18 +593,27 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   const bool all_short_modes = !detect && opts->fixed_block_modes[0] != 0 && opts->fixed_block_modes[1] != 0 &&
                                opts->fixed_block_modes[2] != 0;
   bool speculate = (all_long_modes || all_short_modes) && !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;
+  bool quantize32 = !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;   // exact coefficients, binary32 quantization with the guard (below)
   int64_t probe_frames = 0;
-  if (speculate && ctx->spec_mode == 1) {
-    // adaptive: look at what the previous speculative call had to redo (its kernels have normally finished by now).
-    // Signals whose spectrum is far from flat (tones) fail the guard band for most units; then the speculative pass
-    // is wasted work, so such streams go straight to the exact kernels, with a fresh probe every 16th call.
-    unsigned long long tot[2];
+  if (quantize32 && ctx->spec_mode == 1) {
+    // adaptive: look at what the previous calls had to redo (their kernels have normally finished by now)
+    unsigned long long tot[4];
     if (hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
         hipStreamSynchronize(ctx->stream) == hipSuccess) {
       const unsigned long long du = tot[0] - ctx->spec_seen[0], dr = tot[1] - ctx->spec_seen[1];
       if (du > 0) { ctx->spec_last_fraction = (double)dr / (double)du; ctx->spec_exact_calls = 0; }
       ctx->spec_seen[0] = tot[0]; ctx->spec_seen[1] = tot[1];
+      const unsigned long long qu = tot[2] - ctx->q32_seen[0], qr = tot[3] - ctx->q32_seen[1];
+      if (qu > 0) { ctx->q32_last_fraction = (double)qr / (double)qu; ctx->q32_off_calls = 0; }
+      ctx->q32_seen[0] = tot[2]; ctx->q32_seen[1] = tot[3];
     }
+    // Material coded with long word lengths (tones: 12-16 bits) leaves binary32 too few fraction bits to certify a
+    // truncation; packing twice is then a loss, so such streams keep the binary64 packing, probed again every 16th call.
+    if (ctx->q32_last_fraction > 0.10 && ctx->q32_off_calls < 15) { quantize32 = false; ctx->q32_off_calls++; }
+  }
+  if (speculate && ctx->spec_mode == 1) {
+    // Signals whose spectrum is far from flat (tones) fail the guard band of the speculative analysis for most units;
+    // then the speculative pass is wasted work, so such streams go straight to the exact kernels.
     if (ctx->spec_last_fraction > 0.30) {
       // exact kernels for this call; every 16th call a slice at its start is speculated to see whether the material
       // has changed (a whole speculative call on tonal material costs three times an exact one)
@@ -677,7 +690,24 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       HIP_TRY(hipStreamWaitEvent(sB, ctx->ev_ana[p], 0));
     }
     { ScopedTiming t(ctx, K_ALLOCATE, sB); c1k_launch_allocate(L, sB); }
-    if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, all_long, sB); }
+    if (L.units && quantize32) {
+      // The coefficients are the reference's, and still the quantization need not be done in binary64: the packing
+      // kernel of the speculative path with a bound of zero forms |x| norm + 0.5 in binary32 and accepts a mantissa only
+      // when no value within the roundings of that (norm32 against norm, the fused operation, the reference's own
+      // two) truncates differently; the few units it lists (and anything not finite) are packed again by the exact kernel.
+      ScopedTiming t(ctx, K_PACK, sB);
+      L.eps = ctx->d_eps[p];
+      L.redo_count = ctx->d_redo[p];
+      L.redo_list = ctx->d_redo[p] + 4;
+      HIP_TRY(hipMemsetAsync(L.eps, 0, (size_t)n * channels * kEpsFloats * sizeof(float), sB));
+      HIP_TRY(hipMemsetAsync(L.redo_count, 0, sizeof(uint32_t), sB));
+      c1k_launch_pack_spec(L, all_long, sB);
+      C1EncodeLaunch R = L;
+      R.unit_list = L.redo_list;
+      R.unit_count = L.redo_count;
+      c1k_launch_pack(R, all_long, sB);
+      c1k_launch_spec_totals(ctx->d_spec_totals + 2, (uint64_t)(n * channels), L.redo_count, sB);
+    } else if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, all_long, sB); }
     if (piped) HIP_TRY(hipEventRecord(ctx->ev_free[p], sB));
   }
   if (piped) {
@@ -805,8 +835,8 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   hipError_t me = hipMalloc(&ctx->d_tables, sizeof(C1DevTables));
   if (me == hipSuccess) me = hipMalloc(&ctx->d_opts, sizeof(C1DevEncOpts));
   if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
-  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, 2 * sizeof(unsigned long long));
-  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, 2 * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, 4 * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, 4 * sizeof(unsigned long long));
   ctx->spec_tables_ok = h->spec_ok != 0;
   {
     const char *sp = getenv("C1_SPEC");       // 0 exact only, 1 adaptive (default), 2 always speculate
@@ -893,6 +923,8 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
   ctx->spec_mode = mode;
   ctx->spec_last_fraction = 0.0;
   ctx->spec_exact_calls = 0;
+  ctx->q32_last_fraction = 0.0;
+  ctx->q32_off_calls = 0;
   return C1_OK;
 }
 
@@ -913,9 +945,22 @@ int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int
   if (units) *units = tot[0];
   if (redone) *redone = tot[1];
   if (reset) {
-    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, sizeof tot, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, 4 * sizeof(unsigned long long), ctx->stream));
     ctx->spec_seen[0] = ctx->spec_seen[1] = 0;
+    ctx->q32_seen[0] = ctx->q32_seen[1] = 0;
   }
+  return C1_OK;
+}
+
+int c1_ctx_quantization_stats(c1_ctx *ctx, uint64_t *units, uint64_t *repacked) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  unsigned long long tot[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (units) *units = tot[2];
+  if (repacked) *repacked = tot[3];
   return C1_OK;
 }
 

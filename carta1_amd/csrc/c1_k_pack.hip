@@ -228,7 +228,9 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
       const int pos0 = (int)((d0 >> 5) & 0x7ff) + slot_j[0] * (int)(d0 & 31);
       int cnt = pos0 & 31, wi = pos0 >> 5;
       uint64_t acc = 0;
-      float worst = 0.0f;                                        // largest |fract - 1/2| + et of the lane
+      uint32_t worst = 0u;                                       // largest |fract - 1/2| + et of the lane, as a bit pattern: for values
+                                                                 // >= 0 the unsigned order is the numeric one, and infinities and NaNs
+                                                                 // (coefficients that are not finite) come out on top instead of being dropped
 #pragma unroll
       for (int p = 0; p < 4; p++) {
         float tt[2];
@@ -246,15 +248,15 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
           acc = (acc << bits) | v;
           cnt += bits;
         }
-        worst = fmaxf(worst, fmaxf(tt[0], tt[1]));
+        worst = max(worst, max(__float_as_uint(tt[0]), __float_as_uint(tt[1])));
         const bool full = cnt >= 32;
         const uint32_t w = full ? (uint32_t)(acc >> ((cnt - 32) & 31)) : 0u;
-        atomicOr(&S.words[wi], w);
+        if (w != 0u) atomicOr(&S.words[wi], w);                 // lanes with nothing to add stay out: atomics of many lanes on one word serialise
         cnt = full ? cnt - 32 : cnt;
         wi += full ? 1 : 0;
       }
-      atomicOr(&S.words[wi], (uint32_t)(acc << ((32 - cnt) & 63)));   // the low cnt bits are the unwritten ones (cnt = 0: nothing)
-      doubtful = !(worst < 0.49999988f);                          // 1/2 - 2^-23 (non-finite data: the analysis has flagged the unit)
+      { const uint32_t w = (uint32_t)(acc << ((32 - cnt) & 63)); if (w != 0u) atomicOr(&S.words[wi], w); }   // the low cnt bits are the unwritten ones (cnt = 0: nothing)
+      doubtful = !(worst < 0x3EFFFFFCu);                          // 0.49999988 = 1/2 - 2^-23
     } else {
     uint64_t acc = 0;
     int cnt = -1, wi = 0;

@@ -118,6 +118,10 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode);
 /* units encoded through the speculative pass and units among them that were redone exactly, since the context was
  * created (or since the last call with reset != 0); synchronises the context's stream */
 int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset);
+/* The exact paths (transient detection, mixed fixed modes, streams the adaptive mode keeps off the speculative analysis)
+ * quantize the reference's coefficients in binary32 with the same guard band and pack the few units it cannot certify
+ * again in binary64: units packed that way so far and units packed twice (cleared by c1_ctx_speculation_stats(reset)). */
+int c1_ctx_quantization_stats(c1_ctx *ctx, uint64_t *units, uint64_t *repacked);
 
 /* Decoder arithmetic.  0 (default): the reference's -- binary64 operations, binary32 at every typed-array store --
  * decoded PCM bit-identical to the reference.  1: the same computation in binary32 throughout; the PCM then differs
