@@ -240,6 +240,17 @@ def test_edge_cases_against_reference(ctx):
     want, _ = O.encode_stream([wild], fixed_modes=(0, 0, 0))
     got = ctx.encode([wild], c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]}))
     assert np.array_equal(got, want)
+    # the same through the exact paths, whose packing quantizes in binary32 behind a guard band and must hand
+    # everything it cannot certify (and anything not finite) to the binary64 kernel
+    ctx.set_speculation(2)                       # not adaptive: the streams before this one may have switched it off
+    before = ctx.quantization_stats()
+    for opts, fm in (({'fixedBlockModes': [0, 2, 0]}, (0, 2, 0)), ({}, None), ({'transientThresholdLow': 0.1}, None)):
+        want, _ = O.encode_stream([wild], fixed_modes=fm, threshold=opts.get('transientThresholdLow', 1.0))
+        got = ctx.encode([wild], c1.EncoderOptions(opts))
+        assert np.array_equal(got, want), opts
+    after = ctx.quantization_stats()
+    ctx.set_speculation(1)
+    assert after[0] - before[0] == 3 * 4 and after[1] > before[1]            # 4 units per call; the wild ones were packed twice
 
 
 def test_aea_round_trip_api(ctx):
