@@ -36,7 +36,7 @@ namespace {
 // Heaps live in LDS as heap[slot][lane] (64 dwords per slot: conflict-free, the two children of a node one
 // ds_read2st64 apart).  An entry that leaves the heap is parked, rank cleared, in the slot the shrinking
 // heap frees, so when the loop ends slots [0, initial size) hold every BFU with its final word length.
-constexpr int kHeapSlotsPerLane = 52 + 2;   // + two zero sentinels behind the last slot
+constexpr int kHeapSlotsPerLane = 52 + 1;   // + one zero sentinel behind the last slot (13 568 bytes per wave: 12 waves per CU; 54 rows leave 11)
 constexpr uint32_t kLow = 0x1FFFFFu;
 constexpr int kCandBytes = kCandidateBytes;  // per unit: 8 totals (double) + 8 x 32-byte results + 8 lower bounds
 constexpr double kAlive = -1.0;              // total of a candidate that may still win and has not been evaluated (real totals are >= 0)
@@ -59,8 +59,10 @@ __device__ __forceinline__ void heap_sift_down(uint32_t *hp, int sentinel, int i
     active = moved;
     if (__builtin_amdgcn_ballot_w64(active) == 0) break;
     i = moved ? 2 * i + 1 + (take_r ? 1 : 0) : i;
-    const uint32_t *src = hp + min(2 * i + 1, sentinel) * 64;
-    el = src[0];
+    // children 2i+1, 2i+2; a node without children reads (slot 51, sentinel) and its left value is masked
+    const int l = 2 * i + 1;
+    const uint32_t *src = hp + min(l, sentinel - 1) * 64;
+    el = l < sentinel ? src[0] : 0u;
     er = src[64];
   }
 }
