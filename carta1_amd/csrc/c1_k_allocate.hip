@@ -137,8 +137,9 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
     const bool tl0 = !tr0 && r1 > vmax;
     const bool mv0 = sift && (tr0 || tl0);
     if (sift) r0 = mv0 ? (tr0 ? r2 : r1) : v;
-    if (__builtin_amdgcn_ballot_w64(mv0) != 0) {
-      // level 1: the chosen child's children are slots 3,4 or 5,6
+    {
+      // level 1: the chosen child's children are slots 3,4 or 5,6.  (No "does any lane still move?" test in front of
+      // levels 1 and 2: among 64 heaps one nearly always does, and the test costs more than the level it would skip.)
       const int i1 = tr0 ? 2 : 1;
       const uint32_t *src = hp + (2 * i1 + 1) * 64;
       const uint32_t el = src[0], er = src[64];
@@ -147,7 +148,7 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
       const bool mv1 = mv0 && (tr1 || tl1);
       const uint32_t val = mv1 ? (tr1 ? er : el) : v;
       if (mv0) { if (tr0) r2 = val; else r1 = val; }
-      if (__builtin_amdgcn_ballot_w64(mv1) != 0) {
+      {
         const int i2 = 2 * i1 + 1 + (tr1 ? 1 : 0);
         const uint32_t *s2 = hp + (2 * i2 + 1) * 64;     // i2 <= 6: children 7..14 always inside the lane's slots
         heap_sift_down(hp, 52, i2, v, s2[0], s2[64], mv1);
