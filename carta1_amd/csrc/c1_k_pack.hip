@@ -150,21 +150,27 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
   // loop body exists twice with the sets swapped, so nothing is copied from one iteration to the next (the
   // h0 = h1, h1 = h2, x = xn rotation of a three-deep pipeline was 22 of the kernel's 310 vector instructions per unit).
   // The block modes a mixed-mode batch needs to address the next unit's coefficients are fetched one unit earlier.
-  auto modes_of = [&](int64_t pos) -> uint32_t {
+  // In list mode the index of a unit is itself a load: it is fetched two units ahead (a wave-uniform scalar), so that
+  // the loads of the unit in flight never wait for it.
+  auto modes_of_unit = [&](int64_t unit) -> uint32_t {
     if constexpr (ALL_LONG) return 0u;
-    else return reinterpret_cast<const uint32_t *>(L.side + unit_at(pos) * kSideBytes)[13];
+    else return reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes)[13];
   };
-  PackHeader hA = pack_load_header<SPEC>(L, unit_at(u_first), lane), hB;
+  auto clamped = [&](int64_t pos) -> int64_t { return pos < units_total ? pos : units_total - 1; };
+  int64_t unit_cur = unit_at(u_first), unit_nxt = unit_at(clamped(u_first + stride));
+  PackHeader hA = pack_load_header<SPEC>(L, unit_cur, lane), hB;
   float xA[8], xB[8];
-  load_coefs(unit_at(u_first), modes_of(u_first), xA);
-  uint32_t modes_next = modes_of(u_first + stride < units_total ? u_first + stride : u_first);
+  load_coefs(unit_cur, modes_of_unit(unit_cur), xA);
+  uint32_t modes_next = modes_of_unit(unit_nxt);
   auto step = [&](const PackHeader &h0, const float (&x)[8], PackHeader &hn, float (&xn)[8], int64_t pos) {
-    const int64_t unit = unit_at(pos);
-    // ---- issue the loads of the unit ahead ----
-    const int64_t u1 = pos + stride, u2 = pos + 2 * stride;
-    hn = pack_load_header<SPEC>(L, unit_at(u1 < units_total ? u1 : pos), lane);
-    load_coefs(unit_at(u1 < units_total ? u1 : pos), modes_next, xn);
-    modes_next = modes_of(u2 < units_total ? u2 : pos);
+    const int64_t unit = unit_cur;
+    // ---- issue the loads of the unit ahead, and the index of the one after it ----
+    hn = pack_load_header<SPEC>(L, unit_nxt, lane);
+    load_coefs(unit_nxt, modes_next, xn);
+    const int64_t unit_nn = unit_at(clamped(pos + 2 * stride));
+    modes_next = modes_of_unit(unit_nn);
+    unit_cur = unit_nxt;
+    unit_nxt = unit_nn;
     // ---- this unit ----
     const uint32_t a7 = h0.al7;
     const bool fallback = (a7 >> 27) & 1;
