@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
       const int B = 212 * 8 - 40 - 10 * n;
       float lo = have_prev ? x_prev - 0.05f : __builtin_fmaf(la_slope, (float)smin, la_off) - 17.0f;
       float hi = have_prev ? x_prev + 3.15f : __builtin_fmaf(la_slope, (float)smax, la_off);
-      const int iters = __builtin_amdgcn_ballot_w64(mine && !have_prev) != 0 ? 10 : 6;
+      const int iters = __builtin_amdgcn_ballot_w64(mine && !have_prev) != 0 ? 8 : 5;
       for (int it = 0; it < iters; it++) {
         const float x = 0.5f * (lo + hi);
         const _Float16 by = (_Float16)(la_off - x - 0.5f);
