@@ -324,12 +324,6 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 constexpr int kSpecsHost[52] = {8, 8, 8, 8, 4, 4, 4, 4, 8, 8, 8, 8, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 9, 9, 9, 9, 10, 10, 10, 10,
                                 12, 12, 12, 12, 12, 12, 12, 12, 20, 20, 20, 20, 20, 20, 20, 20};   // kSpecs as compile-time constants
-__device__ __forceinline__ int relaxed_bits(float y) {      // word length in bits the relaxed problem gives a BFU with log2(biasedSF / lambda) = y
-  const int e = (int)__builtin_floorf(y);
-  const int bits = e < 2 ? 2 : (e > 16 ? 16 : e);
-  return y > 0.19264507f ? bits : 0;                        // two bits beat none iff lambda < 0.875 biasedSF
-}
-
 __global__ __launch_bounds__(256) void k_alloc_bound(C1EncodeLaunch L) {
   __shared__ double biased_s[64];
   const C1DevEncOpts *O = L.opts;
