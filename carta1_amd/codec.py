@@ -130,6 +130,12 @@ class Context:
         capi.check(capi.load().c1_ctx_quantization_stats(self._h, C.byref(u), C.byref(r)))
         return int(u.value), int(r.value)
 
+    def detection_stats(self):
+        """(units whose block modes the speculative transient detector decided, units among them rechecked exactly)"""
+        u, r = C.c_uint64(0), C.c_uint64(0)
+        capi.check(capi.load().c1_ctx_detection_stats(self._h, C.byref(u), C.byref(r)))
+        return int(u.value), int(r.value)
+
     def encode(self, channels, options=None, halo_frames=0, out=None):
         """channels: list of 1 or 2 float32 arrays, each (halo_frames + frames) * 512 samples.
         Returns uint8 [frames * nch, 212], units interleaved L,R.  `out`: optional preallocated result (when it
@@ -226,6 +232,20 @@ class Context:
         capi.check(capi.load().c1_detect_stages_device(
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
             C.c_void_p(mags_ptr), C.c_void_p(modes_ptr)))
+
+    def detect_scores_device(self, pcm_ptrs, frames, scores_ptr, modes_ptr, open_ptr, options=None, halo_frames=0, speculative=True):
+        """Per unit and band {lo, hi}: the speculative detector's interval for the transient score, or the reference's
+        score twice; the block modes after the exact recheck; how many units the interval left open."""
+        opts = (options or EncoderOptions()).to_c()
+        capi.check(capi.load().c1_detect_scores_device(
+            self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts), 1 if speculative else 0,
+            C.c_void_p(scores_ptr), C.c_void_p(modes_ptr), C.c_void_p(open_ptr)))
+
+    def log2f_error(self, first_bits, count):
+        """(max relative error in units of 2^-24, max absolute error near 1) of the device's binary32 log2 over a range of bit patterns"""
+        out = (C.c_double * 2)()
+        capi.check(capi.load().c1_log2f_error_device(self._h, first_bits, count, out))
+        return float(out[0]), float(out[1])
 
     def libm_device(self, fn, in_ptr, out_ptr, n):
         """Math.log / exp / log1p / log10 (fn 0..3) as the detector's kernels evaluate them, on n device doubles."""

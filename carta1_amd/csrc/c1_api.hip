@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "c1_internal.h"
+#include "c1_detect_bound.h"
 
 #pragma clang fp contract(off)
 
@@ -156,6 +157,11 @@ void build_spec_tables(const c1_tables &t, C1DevTables *d) {
   }
   d->spec_cz[3] = d->spec_cw[3] = d->spec_cl[3] = d->spec_cz_short[3] = d->spec_cw_short[3] = d->spec_cl_short[3] = 0.0f;
   d->spec_eabs = (float)std::ldexp(1.0, -70);
+  // speculative transient detector (c1_detect_bound.h): Delta_b = K u theta sqrt(n) ||band samples|| + eabs
+  for (int b = 0; b < 3; b++)
+    d->det_ck[b] = round_up_f32(std::ldexp(1.0, -24) * C1_DET_THETA * (b == 2 ? C1_DET_K256 * 16.0 : C1_DET_K128 * std::sqrt(128.0)));
+  d->det_ck[3] = 0.0f;
+  d->det_eabs = round_up_f32(C1_DET_EABS);
   d->spec_ok = ok ? 1 : 0;
 }
 
@@ -387,6 +393,10 @@ struct c1_ctx {
   double q32_last_fraction = 0.0;
   int q32_off_calls = 0;
   unsigned long long q32_seen[2] = {0, 0};
+  // speculative transient detector: d_spec_totals[4] units decided, [5] of them by the exact recheck
+  double det_last_fraction = 0.0;
+  int det_off_calls = 0;
+  unsigned long long det_seen[2] = {0, 0};
   // transient-detection workspace (allocated on first use): band samples, feature sums, block modes
   int64_t det_units = 0;
   float *d_bands[2] = {nullptr, nullptr};
@@ -462,7 +472,7 @@ int ensure_detect_workspace(c1_ctx *ctx, int64_t units) {
     HIP_TRY(hipMalloc(&ctx->d_bands[p], (size_t)(units + C1_MAX_CHANNELS) * 512 * sizeof(float)));
     HIP_TRY(hipMalloc(&ctx->d_feat[p], (size_t)(units + C1_MAX_CHANNELS) * kFeatureWsDoubles * sizeof(double)));
     HIP_TRY(hipMalloc(&ctx->d_modes[p], (size_t)units));
-    HIP_TRY(hipMalloc(&ctx->d_lists[p], ((size_t)units * 2 + 4) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_lists[p], ((size_t)units * 3 + 4) * sizeof(uint32_t)));
   }
   ctx->det_units = units;
   return C1_OK;
@@ -594,10 +604,12 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
                                opts->fixed_block_modes[2] != 0;
   bool speculate = (all_long_modes || all_short_modes) && !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;
   bool quantize32 = !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;   // exact coefficients, binary32 quantization with the guard (below)
+  static const bool det_spec_env_off = getenv("C1_DETECT_SPEC") && atoi(getenv("C1_DETECT_SPEC")) == 0;   // experiments: exact detector, the rest as usual
+  bool detect_spec = detect && !taps && ctx->spec_tables_ok && ctx->spec_mode != 0 && !det_spec_env_off;   // binary32 transient detector with a score interval
   int64_t probe_frames = 0;
   if (quantize32 && ctx->spec_mode == 1) {
     // adaptive: look at what the previous calls had to redo (their kernels have normally finished by now)
-    unsigned long long tot[4];
+    unsigned long long tot[6];
     if (hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
         hipStreamSynchronize(ctx->stream) == hipSuccess) {
       const unsigned long long du = tot[0] - ctx->spec_seen[0], dr = tot[1] - ctx->spec_seen[1];
@@ -606,7 +618,13 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       const unsigned long long qu = tot[2] - ctx->q32_seen[0], qr = tot[3] - ctx->q32_seen[1];
       if (qu > 0) { ctx->q32_last_fraction = (double)qr / (double)qu; ctx->q32_off_calls = 0; }
       ctx->q32_seen[0] = tot[2]; ctx->q32_seen[1] = tot[3];
+      const unsigned long long tu = tot[4] - ctx->det_seen[0], tr = tot[5] - ctx->det_seen[1];
+      if (tu > 0) { ctx->det_last_fraction = (double)tr / (double)tu; ctx->det_off_calls = 0; }
+      ctx->det_seen[0] = tot[4]; ctx->det_seen[1] = tot[5];
     }
+    // A listed unit costs two exact transient FFTs where the exact detector spends one per unit: past a fifth of the
+    // units left open the speculative detector is a loss, and such a stream keeps the exact one (probed every 16th call).
+    if (detect_spec && ctx->det_last_fraction > 0.20 && ctx->det_off_calls < 15) { detect_spec = false; ctx->det_off_calls++; }
     // Material coded with long word lengths (tones: 12-16 bits) leaves binary32 too few fraction bits to certify a
     // truncation; packing twice is then a loss, so such streams keep the binary64 packing, probed again every 16th call.
     if (ctx->q32_last_fraction > 0.10 && ctx->q32_off_calls < 15) { quantize32 = false; ctx->q32_off_calls++; }
@@ -680,7 +698,8 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       ScopedTiming t(ctx, K_ANALYSIS, sA);
       if (all_long) c1k_launch_analysis_long(L, sA);
       else if (detect) {
-        c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], ctx->d_lists[p], sA);
+        c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], ctx->d_lists[p], detect_spec, nullptr, sA);
+        if (detect_spec) c1k_launch_spec_totals(ctx->d_spec_totals + 4, (uint64_t)(n * channels), ctx->d_lists[p] + 2, sA);
         if (L.bands) HIP_TRY(hipMemcpyAsync(L.bands, ctx->d_bands[p] + (size_t)channels * 512, (size_t)n * channels * 512 * sizeof(float),
                                             hipMemcpyDeviceToDevice, sA));
       } else c1k_launch_analysis(L, false, sA);
@@ -835,8 +854,8 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   hipError_t me = hipMalloc(&ctx->d_tables, sizeof(C1DevTables));
   if (me == hipSuccess) me = hipMalloc(&ctx->d_opts, sizeof(C1DevEncOpts));
   if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
-  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, 4 * sizeof(unsigned long long));
-  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, 4 * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, 6 * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, 6 * sizeof(unsigned long long));
   ctx->spec_tables_ok = h->spec_ok != 0;
   {
     const char *sp = getenv("C1_SPEC");       // 0 exact only, 1 adaptive (default), 2 always speculate
@@ -925,6 +944,8 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
   ctx->spec_exact_calls = 0;
   ctx->q32_last_fraction = 0.0;
   ctx->q32_off_calls = 0;
+  ctx->det_last_fraction = 0.0;
+  ctx->det_off_calls = 0;
   return C1_OK;
 }
 
@@ -945,9 +966,10 @@ int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int
   if (units) *units = tot[0];
   if (redone) *redone = tot[1];
   if (reset) {
-    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, 6 * sizeof(unsigned long long), ctx->stream));
     ctx->spec_seen[0] = ctx->spec_seen[1] = 0;
     ctx->q32_seen[0] = ctx->q32_seen[1] = 0;
+    ctx->det_seen[0] = ctx->det_seen[1] = 0;
   }
   return C1_OK;
 }
@@ -961,6 +983,18 @@ int c1_ctx_quantization_stats(c1_ctx *ctx, uint64_t *units, uint64_t *repacked) 
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (units) *units = tot[2];
   if (repacked) *repacked = tot[3];
+  return C1_OK;
+}
+
+int c1_ctx_detection_stats(c1_ctx *ctx, uint64_t *units, uint64_t *rechecked) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (units) *units = tot[4];
+  if (rechecked) *rechecked = tot[5];
   return C1_OK;
 }
 
@@ -1026,9 +1060,52 @@ int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   L.coefs = ctx->d_coefs[0]; L.side = ctx->d_side[0]; L.alloc = ctx->d_alloc[0]; L.cand = ctx->d_cand[0];
   L.work_count = ctx->d_work[0]; L.work_list = ctx->d_work[0] + 4; L.sel_list = ctx->d_work[0] + 4 + (size_t)ctx->ws_units * 7;
   L.mags = mags;
-  c1k_launch_detect(L, ctx->d_bands[0], ctx->d_feat[0], ctx->d_modes[0], ctx->d_lists[0], ctx->stream);
+  c1k_launch_detect(L, ctx->d_bands[0], ctx->d_feat[0], ctx->d_modes[0], ctx->d_lists[0], false, nullptr, ctx->stream);
   if (modes) HIP_TRY(hipMemcpyAsync(modes, ctx->d_modes[0], (size_t)units, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+int c1_detect_scores_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                            const c1_encode_options *opts, int speculative, double *scores, uint8_t *modes, uint32_t *open_units) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
+  if (!pcm || !opts) return fail(C1_ERR_ARG, "NULL argument");
+  if (opts->fixed_block_modes[0] >= 0) return fail(C1_ERR_ARG, "the detector taps need transient detection (fixed_block_modes -1)");
+  if (frames > kMaxChunkFrames) return fail(C1_ERR_ARG, "stage taps are not chunked: at most %lld frames per call", (long long)kMaxChunkFrames);
+  if (speculative && !ctx->spec_tables_ok) return fail(C1_ERR_ARG, "the installed tables do not admit the speculative paths");
+  for (int c = 0; c < channels; c++)
+    if (!pcm[c] || ((uintptr_t)pcm[c] & 15)) return fail(C1_ERR_ARG, "pcm[%d] must be a 16-byte aligned device pointer", c);
+  if ((rc = upload_opts(ctx, opts))) return rc;
+  if (frames == 0) return C1_OK;
+  const int64_t units = frames * channels;
+  if ((rc = ensure_detect_workspace(ctx, units))) return rc;
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c];
+  L.channels = channels; L.frames = frames; L.halo_frames = halo_frames;
+  L.tables = ctx->d_tables; L.opts = ctx->d_opts;
+  c1k_launch_detect(L, ctx->d_bands[0], ctx->d_feat[0], ctx->d_modes[0], ctx->d_lists[0], speculative != 0, scores, ctx->stream);
+  if (modes) HIP_TRY(hipMemcpyAsync(modes, ctx->d_modes[0], (size_t)units, hipMemcpyDeviceToDevice, ctx->stream));
+  if (open_units) HIP_TRY(hipMemcpyAsync(open_units, ctx->d_lists[0] + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+int c1_log2f_error_device(c1_ctx *ctx, uint32_t first_bits, uint64_t count, double *out_host) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!out_host) return fail(C1_ERR_ARG, "out is NULL");
+  if (first_bits < 0x00800000u || (uint64_t)first_bits + count > 0x7f800000ull) return fail(C1_ERR_ARG, "range must stay within the normal positive binary32 numbers");
+  if ((rc = ensure_io(ctx, 16))) return rc;
+  c1k_launch_log2f_error(first_bits, count, reinterpret_cast<unsigned long long *>(ctx->d_io), ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_host, ctx->d_io, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return C1_OK;
 }
 

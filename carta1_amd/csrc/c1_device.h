@@ -319,6 +319,54 @@ __device__ __forceinline__ double2 table_pair(TablesRsrc R, int byte_offset) {
   __builtin_memcpy(&d, &v, sizeof d);
   return d;
 }
+// =====================================================================================================
+// binary32 helpers of the speculative kernels (c1_k_spec.hip, the speculative transient detector in c1_k_detect.hip)
+// =====================================================================================================
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// every lane of a 16-lane row ends with the row's sum ((q0 + q1) + (q2 + q3), q = ((v0 + v1) + (v2 + v3)) of a quad)
+__device__ __forceinline__ float row_allreduce(float x) {
+  x += dpp_read<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_read<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_read<0x141>(x);   // row_half_mirror
+  x += dpp_read<0x140>(x);   // row_mirror
+  return x;
+}
+__device__ __forceinline__ float lane_value(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ float wave_sum(float x) {
+  x = row_allreduce(x);
+  return (lane_value(x, 0) + lane_value(x, 16)) + (lane_value(x, 32) + lane_value(x, 48));
+}
+
+// ---- packed binary32 arithmetic -------------------------------------------------------------------------------------
+// On CDNA a wave64 vector instruction occupies its SIMD for four cycles whatever its type; the binary32 peak needs the
+// packed forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations per lane and instruction
+// on an aligned register pair).  The kernel is written on 2-vectors so that every pair it operates on is one the data
+// already forms: the (even, odd) sample pairs of a 16-byte LDS read, (re, im) of a complex point.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f V2(float x, float y) { v2f r; r.x = x; r.y = y; return r; }
+
+// Multiplying by +-1 is exact, so "negate one half" and "swap and negate" ride on an FMA or a product with one of
+// these constant pairs instead of costing sign-bit instructions of their own.
+#define PMN V2(1.0f, -1.0f)
+#define PNM V2(-1.0f, 1.0f)
+// complex product (x.x + i x.y)(w.x + i w.y): two products rounded, then two fused
+__device__ __forceinline__ v2f cmul32(v2f x, v2f w) {
+  const v2f wr = w.yx * PNM;                             // (-w.y, w.x), exact
+  const v2f t = x.yy * wr;                               // (-(x.y w.y), x.y w.x)
+  return pk_fma(x.xx, w, t);
+}
+
+__device__ __forceinline__ v2f table_f2(TablesRsrc R, int byte_offset) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(R, byte_offset, 0, 0);
+  v2f d;
+  __builtin_memcpy(&d, &v, sizeof d);
+  return d;
+}
+
 // one radix-2 butterfly of fft.js:46-60 on Float32 points held in registers
 __device__ __forceinline__ void r2_butterfly(float2 &e, float2 &o, const double2 w) {
   const double er = e.x, ei = e.y, orr = o.x, oi = o.y;

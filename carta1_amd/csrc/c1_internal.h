@@ -49,6 +49,9 @@ struct C1DevTables {
   float spec_cz[4], spec_cw[4], spec_cl[4];
   float spec_cz_short[4], spec_cw_short[4], spec_cl_short[4];   // the same for a band coded with short blocks (16-point transforms)
   float spec_eabs;
+  // speculative transient detector (c1_detect_bound.h): Delta_b = det_ck[b] * ||band samples|| + det_eabs, rounded up
+  float det_ck[4];
+  float det_eabs;
   int32_t spec_ok;           // 0: the installed tables fail the structural checks the bound relies on -> exact path only
 };
 
@@ -143,10 +146,13 @@ void c1k_launch_analysis_spec(const C1EncodeLaunch &L, bool all_short, hipStream
 // transient detection: features (runs) -> decisions (per unit) -> MDCT from the stored bands (per unit).
 // bands_ws: (units + channels) * 512 floats, feat_ws: (units + channels) * kFeatureWsDoubles doubles, modes_ws: units bytes
 constexpr int kFeatureWsDoubles = 20;
-// lists_ws: 4 + 2 * units uint32 (two counts, then the all-long and the mixed unit list)
+// lists_ws: 4 + 3 * units uint32 (three counts, then the all-long list, the mixed list, and the units the speculative
+// detector left to the exact recheck).  speculative: binary32 detector with a score interval.
+// score_tap (tests): units * 3 * 2 doubles {lo, hi} (speculative) or {score, score}.  L.coefs null: decisions only.
 void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
-                       hipStream_t stream);
+                       bool speculative, double *score_tap, hipStream_t stream);
 void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream);
+void c1k_launch_log2f_error(uint32_t first, uint64_t count, unsigned long long *out, hipStream_t stream);   // out: 2 x u64 on the device
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_alloc_tap(const C1EncodeLaunch &L, double *out, hipStream_t stream);   // test tap: totals and lower bounds of all candidates
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]

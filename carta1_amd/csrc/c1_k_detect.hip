@@ -1,5 +1,6 @@
 // c1_k_detect.hip -- transient detection pipeline: features (runs), decisions (per unit), MDCT from the stored bands (per unit)
 #include "c1_device.h"
+#include "c1_detect_bound.h"
 
 namespace {
 
@@ -30,6 +31,19 @@ struct alignas(16) DetectLds {
     struct { alignas(16) double term[4][256]; } tt;
   } u;
 };
+// the speculative detector reduces its sums in registers: without the per-bin terms a wave needs 9.4 KB, 4 waves per SIMD
+struct alignas(16) DetectSpecLds {
+  double d1[46];
+  double d2[46];
+  alignas(16) float hbuf[296];
+  alignas(16) float band[512];
+  union alignas(16) {
+    struct { alignas(16) double w1[698]; } q1;
+    struct { alignas(16) double w2[454]; } q2;
+    struct { alignas(16) float2 z[576]; } t;
+  } u;
+};
+static_assert(sizeof(DetectSpecLds) <= 10240, "speculative detector: 16 waves per CU");
 
 __device__ __forceinline__ int tslot(int pos) { return pos + (pos >> 3); }
 
@@ -212,6 +226,40 @@ __global__ void k_libm_tap(int fn, const double *__restrict__ in, double *__rest
   out[i] = fn == 0 ? js_log(x) : (fn == 1 ? js_exp(x) : (fn == 2 ? js_log1p(x) : js_log10(x)));
 }
 
+// ---- lane-only geometry of the transient FFT: lanes 0..15 band 0 (128 points), 16..31 band 1, 32..63 band 2 (256);
+// eight points per lane and round
+struct TGeom {
+  int band, g, S;          // S = N/8: sample stride of round A, point stride of round C
+  int src;                 // band sample of the lane's first round-A input (bit-reversed group)
+  int za, zb, zc, zc_stride;
+  int twb, twc, twc_stride, twd;             // byte offsets into fft_tw (binary64 pairs)
+  int twb32, twc32, twc32_stride, twd32;     // the same entries of tw32 (binary32 pairs)
+  int mag;                 // magnitude index of the lane's first bin; the next bins are S further each
+};
+__device__ __forceinline__ TGeom tfft_geometry(int lane0) {
+  TGeom G;
+  G.band = lane0 < 16 ? 0 : (lane0 < 32 ? 1 : 2);
+  G.g = lane0 - (G.band == 0 ? 0 : (G.band == 1 ? 16 : 32));
+  G.S = G.band == 2 ? 32 : 16;
+  G.src = (G.band == 0 ? 0 : (G.band == 1 ? 128 : 256)) + bitrev(G.g, G.band == 2 ? 5 : 4);
+  const int pbase = G.band == 0 ? 0 : (G.band == 1 ? 128 : 256);
+  G.za = tslot(pbase + 8 * G.g);
+  G.zb = tslot(pbase + 64 * (G.g >> 3) + (G.g & 7));
+  G.zc = tslot(pbase + G.g);
+  G.zc_stride = G.S + G.S / 8;
+  const int eb = 7 + (G.g & 7), ec = (G.band == 2 ? 127 : 63) + G.g, ed = 63 + (G.g & 31);
+  G.twb = (int)offsetof(C1DevTables, fft_tw) + 16 * eb;
+  G.twc = (int)offsetof(C1DevTables, fft_tw) + 16 * ec;
+  G.twc_stride = 16 * G.S;
+  G.twd = (int)offsetof(C1DevTables, fft_tw) + 16 * ed;
+  G.twb32 = (int)offsetof(C1DevTables, tw32) + 8 * eb;
+  G.twc32 = (int)offsetof(C1DevTables, tw32) + 8 * ec;
+  G.twc32_stride = 8 * G.S;
+  G.twd32 = (int)offsetof(C1DevTables, tw32) + 8 * ed;
+  G.mag = (G.band == 0 ? 0 : (G.band == 1 ? 64 : 128)) + G.g;
+  return G;
+}
+
 // Round A of the transient FFT (performFFT, transient.js:17-35): real input, stages h = 1, 2, 4 on the points at
 // bit-reversed positions 8g..8g+7.  Seven of the twelve butterflies have the twiddle (1, 0); when every sample is
 // finite, not -0 and small enough not to overflow they are exact as Float32 adds (see r2_unit_ok), and the
@@ -255,8 +303,240 @@ __device__ __forceinline__ float2 r2_butterfly_e(const float2 e, const float2 o,
   return make_float2(f32(er + xr), f32(ei + xi));
 }
 
-__global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L, float *bands_ws, double *feat_ws) {
-  __shared__ DetectLds S;
+// performFFT (transient.js:17-35) of the three bands in `band`, exactly as the reference rounds it, in radix-8 rounds
+// through `z`; mg = the Float32 magnitudes of the lane's four bins.  Ends with a fence: z may be reused.
+__device__ __forceinline__ void tfft_exact(const float *band, float2 *z, const TGeom &G, TablesPtr T, TablesRsrc RT, float (&mg)[4]) {
+  float2 x[8];
+  {
+    const float *src = band + G.src;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int jr = ((j & 1) << 2) | (j & 2) | (j >> 2);          // bitrev3
+      x[j] = make_float2(src[jr * G.S], 0.0f);
+    }
+  }
+  // twiddles of round B are requested before round A computes, those of round C before round B
+  const double2 w8 = table_pair(RT, G.twb), w16a = table_pair(RT, G.twb + 128), w16b = table_pair(RT, G.twb + 256);
+  const double2 w32a = table_pair(RT, G.twb + 384), w32b = table_pair(RT, G.twb + 512);
+  const double2 w32c = table_pair(RT, G.twb + 640), w32d = table_pair(RT, G.twb + 768);
+  __builtin_amdgcn_s_setprio(0);
+  tfft_round_a(x, T);
+  {
+    float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+#pragma unroll
+    for (int j = 0; j < 4; j++) dst[j] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
+  }
+  __syncthreads();
+  {
+    float2 *p = z + G.zb;                                    // stages 8, 16, 32 on the points p + 8j
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = p[9 * j];
+    r2_butterfly(x[0], x[1], w8); r2_butterfly(x[2], x[3], w8); r2_butterfly(x[4], x[5], w8); r2_butterfly(x[6], x[7], w8);
+    r2_butterfly(x[0], x[2], w16a); r2_butterfly(x[1], x[3], w16b); r2_butterfly(x[4], x[6], w16a); r2_butterfly(x[5], x[7], w16b);
+    r2_butterfly(x[0], x[4], w32a); r2_butterfly(x[1], x[5], w32b); r2_butterfly(x[2], x[6], w32c); r2_butterfly(x[3], x[7], w32d);
+#pragma unroll
+    for (int j = 0; j < 8; j++) p[9 * j] = x[j];
+  }
+  const double2 wDa = table_pair(RT, G.twd), wDb = table_pair(RT, G.twd + 512);
+  const double2 wC0 = table_pair(RT, G.twc), wC1 = table_pair(RT, G.twc + G.twc_stride);
+  const double2 wC2 = table_pair(RT, G.twc + 2 * G.twc_stride), wC3 = table_pair(RT, G.twc + 3 * G.twc_stride);
+  __syncthreads();
+  {
+    // points g + S*t, t = 0..7.  Band 2 first runs stage 64 on them; then stage N/2 (64 for the 128-point
+    // transforms, 128 for the 256-point one) pairs (t, t+4) and only its e-outputs, the bins g + S*t, are needed
+    const float2 *p = z + G.zc;
+#pragma unroll
+    for (int t = 0; t < 8; t++) x[t] = p[t * G.zc_stride];
+    if (G.band == 2) {
+      r2_butterfly(x[0], x[2], wDa); r2_butterfly(x[1], x[3], wDb); r2_butterfly(x[4], x[6], wDa); r2_butterfly(x[5], x[7], wDb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float2 e = r2_butterfly_e(x[i], x[i + 4], i == 0 ? wC0 : (i == 1 ? wC1 : (i == 2 ? wC2 : wC3)));
+      const double r = e.x, im = e.y;
+      mg[i] = f32(sqrt(r * r + im * im));
+    }
+  }
+  __syncthreads();                                           // the per-bin terms reuse the memory of the points
+}
+
+// feature terms per bin, then the reference's 18 sequential sums (transient.js:92-189) -> feat[0..18), nv[3] as int32 behind
+__device__ __forceinline__ void exact_sums(double (*term)[256], const TGeom &G, int lane, const float (&mg)[4], const float (&pmag)[4],
+                                           double *feat) {
+  bool valid[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int g = G.mag + i * G.S;
+    const double cm = (double)mg[i], pm = (double)pmag[i];
+    const double diff = cm - pm;
+    valid[i] = cm > 1e-10;
+    term[0][g] = diff > 0 ? diff : 0.0;            // spectral flux terms (transient.js:96-106)
+    term[1][g] = cm * cm;                          // energy terms (exact product)
+    term[2][g] = valid[i] ? js_log(cm) : 0.0;      // flatness terms (transient.js:126-133)
+    term[3][g] = valid[i] ? cm : 0.0;
+  }
+  int nv_all = 0;
+  {
+    uint64_t m = 0;
+    int n0 = 0, n1 = 0, n2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      m = __ballot(valid[i]);
+      n0 += __popc((uint32_t)m & 0xffffu); n1 += __popc((uint32_t)m >> 16); n2 += __popcll(m >> 32);
+    }
+    nv_all = lane == 0 ? n0 : (lane == 1 ? n1 : n2);
+  }
+  __syncthreads();
+  if (lane < 18) {
+    // 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high}), index ascending
+    const int b = lane / 6, kind = lane - 6 * b;
+    const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
+    const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
+    const int start = g0 + (kind == 5 ? n / 2 : 0);
+    const int len = kind >= 4 ? n / 2 : n;
+    const double2 *arr = reinterpret_cast<const double2 *>(term[which] + start);
+    double acc = 0.0;
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) {
+      if (32 * blk < len) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const double2 v = arr[16 * blk + i]; acc += v.x; acc += v.y; }
+      }
+    }
+    feat[lane] = acc;
+  }
+  if (lane < 3) reinterpret_cast<int *>(feat + 18)[lane] = nv_all;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The speculative detector: the same transient FFT in binary32 on packed (re, im) pairs, any rounding
+// order (c1_detect_bound.h counts its roundings), magnitudes, and per band the sums c1_detect_bound.h turns into an
+// interval for the reference's score.  Row r of the wave (16 lanes) reduces its own ten values with DPP.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf32(v2f &e, v2f &o, const v2f w) {
+  const v2f t = cmul32(o, w);
+  o = e - t;
+  e = e + t;
+}
+__device__ __forceinline__ uint32_t row_allreduce_umax(uint32_t x) {
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+  return x;
+}
+__device__ __forceinline__ void tfft_spec(const float *band, float2 *zf, const TGeom &G, TablesPtr T, TablesRsrc RT, float (&mg)[4],
+                                          float &delta) {
+  v2f *z = reinterpret_cast<v2f *>(zf);
+  float xr[8];
+  {
+    const float *src = band + G.src;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int jr = ((j & 1) << 2) | (j & 2) | (j >> 2);          // bitrev3
+      xr[j] = src[jr * G.S];
+    }
+  }
+  const v2f w8 = table_f2(RT, G.twb32), w16a = table_f2(RT, G.twb32 + 64), w16b = table_f2(RT, G.twb32 + 128);
+  const v2f w32a = table_f2(RT, G.twb32 + 192), w32b = table_f2(RT, G.twb32 + 256);
+  const v2f w32c = table_f2(RT, G.twb32 + 320), w32d = table_f2(RT, G.twb32 + 384);
+  // ---- Delta = K u theta sqrt(n) ||x|| + eabs from the band's own samples (c1_detect_bound.h) ----
+  {
+    float ss = 0.0f;
+    uint32_t am = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ss = __builtin_fmaf(xr[j], xr[j], ss); am = max(am, __float_as_uint(xr[j]) & 0x7fffffffu); }
+    ss = row_allreduce(ss);
+    am = row_allreduce_umax(am);                               // as a bit pattern: NaN and infinity come out on top
+    const float ss_o = __shfl_xor(ss, 16);
+    const uint32_t am_o = (uint32_t)__shfl_xor((int)am, 16);
+    if (G.band == 2) { ss += ss_o; am = max(am, am_o); }
+    const float amax = __uint_as_float(am);
+    // squares of samples below 2^-63 underflow: below 2^-40 take sqrt(n) max|x| instead of the rounded sum
+    const float w_up = amax < 9.094947e-13f ? 16.0f * amax : __builtin_sqrtf(ss) * 1.00001f;
+    delta = am == 0u ? 0.0f : __builtin_fmaf(T->det_ck[G.band], w_up, T->det_eabs) * 1.000001f;
+  }
+  // ---- round A: stages 1, 2, 4 of a real sequence; the rotations by -i are exact ----
+  v2f c[8];
+  {
+    const float a0 = xr[0] + xr[1], a1 = xr[0] - xr[1], a2 = xr[2] + xr[3], a3 = xr[2] - xr[3];
+    const float a4 = xr[4] + xr[5], a5 = xr[4] - xr[5], a6 = xr[6] + xr[7], a7 = xr[6] - xr[7];
+    const float b0 = a0 + a2, b2 = a0 - a2, b4 = a4 + a6, b6 = a4 - a6;
+    constexpr float s = 0.70710678118654752f;
+    const float p = s * (a5 - a7), q = s * (a5 + a7);          // w4 b5 = (p, -q), w6 b7 = (-p, -q)
+    c[0] = V2(b0 + b4, 0.0f); c[4] = V2(b0 - b4, 0.0f);
+    c[2] = V2(b2, -b6); c[6] = V2(b2, b6);
+    c[1] = V2(a1 + p, -a3 - q); c[5] = V2(a1 - p, q - a3);
+    c[3] = V2(a1 - p, a3 - q); c[7] = V2(a1 + p, a3 + q);
+  }
+  {
+    float4 *dst = reinterpret_cast<float4 *>(z + G.za);
+#pragma unroll
+    for (int j = 0; j < 4; j++) dst[j] = make_float4(c[2 * j].x, c[2 * j].y, c[2 * j + 1].x, c[2 * j + 1].y);
+  }
+  __syncthreads();
+  {
+    v2f *p = z + G.zb;                                       // stages 8, 16, 32 on the points p + 8j
+#pragma unroll
+    for (int j = 0; j < 8; j++) c[j] = p[9 * j];
+    bf32(c[0], c[1], w8); bf32(c[2], c[3], w8); bf32(c[4], c[5], w8); bf32(c[6], c[7], w8);
+    bf32(c[0], c[2], w16a); bf32(c[1], c[3], w16b); bf32(c[4], c[6], w16a); bf32(c[5], c[7], w16b);
+    bf32(c[0], c[4], w32a); bf32(c[1], c[5], w32b); bf32(c[2], c[6], w32c); bf32(c[3], c[7], w32d);
+#pragma unroll
+    for (int j = 0; j < 8; j++) p[9 * j] = c[j];
+  }
+  const v2f wDa = table_f2(RT, G.twd32), wDb = table_f2(RT, G.twd32 + 256);
+  const v2f wC0 = table_f2(RT, G.twc32), wC1 = table_f2(RT, G.twc32 + G.twc32_stride);
+  const v2f wC2 = table_f2(RT, G.twc32 + 2 * G.twc32_stride), wC3 = table_f2(RT, G.twc32 + 3 * G.twc32_stride);
+  __syncthreads();
+  {
+    const v2f *p = z + G.zc;
+#pragma unroll
+    for (int t = 0; t < 8; t++) c[t] = p[t * G.zc_stride];
+    if (G.band == 2) { bf32(c[0], c[2], wDa); bf32(c[1], c[3], wDb); bf32(c[4], c[6], wDa); bf32(c[5], c[7], wDb); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const v2f e = c[i] + cmul32(c[i + 4], i == 0 ? wC0 : (i == 1 ? wC1 : (i == 2 ? wC2 : wC3)));
+      mg[i] = __builtin_sqrtf(__builtin_fmaf(e.y, e.y, e.x * e.x));
+    }
+  }
+  __syncthreads();
+}
+
+// the ten sums of c1_detect_bound.h for the lane's row; lane 16 r writes row r of the frame's record
+__device__ __forceinline__ void spec_sums(const TGeom &G, int lane, const float (&mg)[4], const float (&pmag)[4], float delta, float *rec) {
+  // certainly valid: c - Delta > 1e-10; certainly not: c + Delta <= 1e-10 (margins cover the roundings of these lines)
+  const float t_valid = __builtin_fmaf(delta, 1.000001f, 1.0001e-10f);
+  const float t_not = __builtin_fmaf(delta, -1.000001f, 0.9999e-10f);
+  float flux = 0.0f, elo = 0.0f, ehi = 0.0f, slog = 0.0f, sabs = 0.0f, slin = 0.0f, sinv2 = 0.0f, nv = 0.0f, bad = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float cm = mg[i];
+    flux += fmaxf(cm - pmag[i], 0.0f);
+    if (i < 2) elo = __builtin_fmaf(cm, cm, elo); else ehi = __builtin_fmaf(cm, cm, ehi);
+    const bool valid = cm > t_valid, sure = valid || cm < t_not;
+    const float lg = __builtin_amdgcn_logf(cm);                 // v_log_f32: log2, 1 ulp (checked exhaustively, tests/test_gpu_detect_spec.py)
+    const float inv = __builtin_amdgcn_rcpf(cm - delta);
+    slog += valid ? lg : 0.0f;
+    sabs += valid ? fabsf(lg) : 0.0f;
+    slin += valid ? cm : 0.0f;
+    sinv2 = valid ? __builtin_fmaf(inv, inv, sinv2) : sinv2;
+    nv += valid ? 1.0f : 0.0f;
+    bad += sure ? 0.0f : 1.0f;
+  }
+  flux = row_allreduce(flux); elo = row_allreduce(elo); ehi = row_allreduce(ehi);
+  slog = row_allreduce(slog); sabs = row_allreduce(sabs); slin = row_allreduce(slin);
+  sinv2 = row_allreduce(sinv2); nv = row_allreduce(nv); bad = row_allreduce(bad);
+  if ((lane & 15) == 0) {
+    float2 *dst = reinterpret_cast<float2 *>(rec + C1_DET_ROW_FLOATS * (lane >> 4));
+    dst[0] = make_float2(flux, elo); dst[1] = make_float2(ehi, slog); dst[2] = make_float2(sabs, slin);
+    dst[3] = make_float2(sinv2, nv); dst[4] = make_float2(bad, delta);
+  }
+}
+
+template <bool SPEC>
+__global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1EncodeLaunch L, float *bands_ws, double *feat_ws) {
+  __shared__ typename std::conditional<SPEC, DetectSpecLds, DetectLds>::type S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int ch = blockIdx.x % L.channels;
@@ -265,19 +545,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
   for (int i = lane; i < 46; i += 64) { S.d1[i] = 0.0; S.d2[i] = 0.0; }
   for (int i = lane; i < 296; i += 64) S.hbuf[i] = 0.0f;
   float pmag[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // magnitudes of the previous frame at this lane's four bins
-  // ---- lane-only geometry of the transient FFT: lanes 0..15 band 0 (128 points), 16..31 band 1, 32..63 band 2 (256)
-  const int tband = lane0 < 16 ? 0 : (lane0 < 32 ? 1 : 2);
-  const int tg = lane0 - (tband == 0 ? 0 : (tband == 1 ? 16 : 32));
-  const int tS = tband == 2 ? 32 : 16;                                   // N/8: sample stride of round A, point stride of round C
-  const int t_src = (tband == 0 ? 0 : (tband == 1 ? 128 : 256)) + bitrev(tg, tband == 2 ? 5 : 4);
-  const int t_pbase = tband == 0 ? 0 : (tband == 1 ? 128 : 256);
-  const int t_za = tslot(t_pbase + 8 * tg);
-  const int t_zb = tslot(t_pbase + 64 * (tg >> 3) + (tg & 7));
-  const int t_twb = (int)offsetof(C1DevTables, fft_tw) + 16 * (7 + (tg & 7));
-  const int t_zc = tslot(t_pbase + tg), t_zc_stride = tS + tS / 8;
-  const int t_twc = (int)offsetof(C1DevTables, fft_tw) + 16 * ((tband == 2 ? 127 : 63) + tg), t_twc_stride = 16 * tS;
-  const int t_twd = (int)offsetof(C1DevTables, fft_tw) + 16 * (63 + (tg & 31));
-  const int t_mag = (tband == 0 ? 0 : (tband == 1 ? 64 : 128)) + tg;   // mag index of the lane's first bin; next bins + tS
+  const TGeom G = tfft_geometry(lane0);
   const TablesRsrc RT = tables_rsrc(L.tables);
   __syncthreads();
 
@@ -354,111 +622,19 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_features(C1EncodeLaunch L
       dst[64 + lane] = src[64 + lane];
     }
 
-    // ---------------- performFFT (transient.js:17-35) in radix-8 rounds ----------------
-    float2 x[8];
-    {
-      const float *src = S.band + t_src;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int jr = ((j & 1) << 2) | (j & 2) | (j >> 2);          // bitrev3
-        x[j] = make_float2(src[jr * tS], 0.0f);
-      }
-    }
-    // twiddles of round B are requested before round A computes, those of round C before round B
-    const double2 w8 = table_pair(RT, t_twb), w16a = table_pair(RT, t_twb + 128), w16b = table_pair(RT, t_twb + 256);
-    const double2 w32a = table_pair(RT, t_twb + 384), w32b = table_pair(RT, t_twb + 512);
-    const double2 w32c = table_pair(RT, t_twb + 640), w32d = table_pair(RT, t_twb + 768);
-    __builtin_amdgcn_s_setprio(0);
-    tfft_round_a(x, T);
-    float2 *z = S.u.t.z;
-    {
-      float4 *dst = reinterpret_cast<float4 *>(z + t_za);
-#pragma unroll
-      for (int j = 0; j < 4; j++) dst[j] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
-    }
-    __syncthreads();
-    {
-      float2 *p = z + t_zb;                                    // stages 8, 16, 32 on the points p + 8j
-#pragma unroll
-      for (int j = 0; j < 8; j++) x[j] = p[9 * j];
-      r2_butterfly(x[0], x[1], w8); r2_butterfly(x[2], x[3], w8); r2_butterfly(x[4], x[5], w8); r2_butterfly(x[6], x[7], w8);
-      r2_butterfly(x[0], x[2], w16a); r2_butterfly(x[1], x[3], w16b); r2_butterfly(x[4], x[6], w16a); r2_butterfly(x[5], x[7], w16b);
-      r2_butterfly(x[0], x[4], w32a); r2_butterfly(x[1], x[5], w32b); r2_butterfly(x[2], x[6], w32c); r2_butterfly(x[3], x[7], w32d);
-#pragma unroll
-      for (int j = 0; j < 8; j++) p[9 * j] = x[j];
-    }
-    const double2 wDa = table_pair(RT, t_twd), wDb = table_pair(RT, t_twd + 512);
-    const double2 wC0 = table_pair(RT, t_twc), wC1 = table_pair(RT, t_twc + t_twc_stride);
-    const double2 wC2 = table_pair(RT, t_twc + 2 * t_twc_stride), wC3 = table_pair(RT, t_twc + 3 * t_twc_stride);
-    __syncthreads();
     float mg[4];
-    {
-      // points g + tS*t, t = 0..7.  Band 2 first runs stage 64 on them; then stage N/2 (64 for the 128-point
-      // transforms, 128 for the 256-point one) pairs (t, t+4) and only its e-outputs, the bins g + tS*t, are needed
-      const float2 *p = z + t_zc;
+    if constexpr (SPEC) {
+      float delta;
+      __builtin_amdgcn_s_setprio(0);
+      tfft_spec(S.band, S.u.t.z, G, T, RT, mg, delta);
+      if (emit) spec_sums(G, lane, mg, pmag, delta, reinterpret_cast<float *>(feat_ws + slot * kFeatureDoubles));
+    } else {
+      tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
+      if (L.mags && f >= f0) {                                   // stage tap: performFFT's magnitudes (transient.js:17-35)
 #pragma unroll
-      for (int t = 0; t < 8; t++) x[t] = p[t * t_zc_stride];
-      if (tband == 2) {
-        r2_butterfly(x[0], x[2], wDa); r2_butterfly(x[1], x[3], wDb); r2_butterfly(x[4], x[6], wDa); r2_butterfly(x[5], x[7], wDb);
+        for (int i = 0; i < 4; i++) L.mags[((f * L.channels + ch) << 8) + G.mag + i * G.S] = mg[i];
       }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float2 e = r2_butterfly_e(x[i], x[i + 4], i == 0 ? wC0 : (i == 1 ? wC1 : (i == 2 ? wC2 : wC3)));
-        const double r = e.x, im = e.y;
-        mg[i] = f32(sqrt(r * r + im * im));
-      }
-    }
-    __syncthreads();                                           // the per-bin terms reuse the memory of the points
-    if (L.mags && f >= f0) {                                   // stage tap: performFFT's magnitudes (transient.js:17-35)
-#pragma unroll
-      for (int i = 0; i < 4; i++) L.mags[((f * L.channels + ch) << 8) + t_mag + i * tS] = mg[i];
-    }
-    if (emit) {
-      // ---------------- feature terms per bin, then the reference's sequential sums ----------------
-      bool valid[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int g = t_mag + i * tS;
-        const double cm = (double)mg[i], pm = (double)pmag[i];
-        const double diff = cm - pm;
-        valid[i] = cm > 1e-10;
-        S.u.tt.term[0][g] = diff > 0 ? diff : 0.0;            // spectral flux terms (transient.js:96-106)
-        S.u.tt.term[1][g] = cm * cm;                          // energy terms (exact product)
-        S.u.tt.term[2][g] = valid[i] ? js_log(cm) : 0.0;         // flatness terms (transient.js:126-133)
-        S.u.tt.term[3][g] = valid[i] ? cm : 0.0;
-      }
-      int nv_all = 0;
-      {
-        uint64_t m = 0;
-        int n0 = 0, n1 = 0, n2 = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          m = __ballot(valid[i]);
-          n0 += __popc((uint32_t)m & 0xffffu); n1 += __popc((uint32_t)m >> 16); n2 += __popcll(m >> 32);
-        }
-        nv_all = lane == 0 ? n0 : (lane == 1 ? n1 : n2);
-      }
-      __syncthreads();
-      double *feat = feat_ws + slot * kFeatureDoubles;
-      if (lane < 18) {
-        // 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high}), index ascending
-        const int b = lane / 6, kind = lane - 6 * b;
-        const int n = b == 2 ? 128 : 64, g0 = b == 0 ? 0 : (b == 1 ? 64 : 128);
-        const int which = kind == 0 ? 0 : (kind == 2 ? 2 : (kind == 3 ? 3 : 1));
-        const int start = g0 + (kind == 5 ? n / 2 : 0);
-        const int len = kind >= 4 ? n / 2 : n;
-        const double2 *arr = reinterpret_cast<const double2 *>(S.u.tt.term[which] + start);
-        double acc = 0.0;
-#pragma unroll
-        for (int blk = 0; blk < 4; blk++) {
-          if (32 * blk < len) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) { const double2 v = arr[16 * blk + i]; acc += v.x; acc += v.y; }
-          }
-        }
-        feat[lane] = acc;
-      }
-      if (lane < 3) reinterpret_cast<int *>(feat + 18)[lane] = nv_all;
+      if constexpr (!SPEC) { if (emit) exact_sums(S.u.tt.term, G, lane, mg, pmag, feat_ws + slot * kFeatureDoubles); }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) pmag[i] = mg[i];
@@ -487,62 +663,149 @@ __device__ __forceinline__ BandFeatures band_features(const double *s, int nv) {
   return r;
 }
 
-// block modes of one sound unit from the feature sums of its frame and of the previous one (encoder.js:137-143)
-__device__ __forceinline__ int detect_decide_unit(const double *__restrict__ feat_ws, int channels, int64_t unit, int halo_frames,
-                                                       const C1DevTables *tables, const C1DevEncOpts *opts) {
-  const int64_t f = unit / channels;
-  const double *cur = feat_ws + (unit + channels) * kFeatureDoubles;
-  const double *prev = cur - (int64_t)channels * kFeatureDoubles;
-  const bool have_prev = (f - 1 >= -(int64_t)halo_frames);      // else the zero state of a fresh BufferPool
-  const double log1p10 = tables->log1p10, threshold = opts->threshold;
-  int mode_byte = 0;
-  for (int b = 0; b < 3; b++) {
-    const BandFeatures c = band_features(cur + 6 * b, reinterpret_cast<const int *>(cur + 18)[b]);
-    double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;
-    if (have_prev) {
-      const BandFeatures p = band_features(prev + 6 * b, reinterpret_cast<const int *>(prev + 18)[b]);
-      prev_flat = p.flat; prev_hf = p.hf; prev_e = p.energy;
-    }
-    const double ce = c.energy > 1e-10 ? c.energy : 1e-10;     // calculateEnergyChange :172-189
-    const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
-    const double db = 10.0 * js_log10(ce / pe);
-    const double e_change = db > 0 ? db : 0.0;
-    const double flat_c = sqrt(fabs(c.flat - prev_flat));       // calculateTransientScore :197-226
-    const double hf_c = js_log1p(fabs(c.hf - prev_hf) * 10.0) / log1p10;
-    const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
-    const double score = (c.flux + flat_c + hf_c + e_c) / 4.0;
-    const int mode = (score > threshold) ? (b + 1 > 2 ? b + 1 : 2) : 0;   // encoder.js:143
-    mode_byte |= mode << (2 * b);
+// block mode of band b of one sound unit from the feature sums of its frame (`cur`: 18 sums, nv[3] behind) and of the
+// previous one (`prev`, or null for the zero state of a fresh BufferPool) (encoder.js:137-143)
+__device__ __forceinline__ int detect_band_mode(const double *cur, const double *prev, int b, double log1p10, double threshold,
+                                                double *score_out) {
+  const BandFeatures c = band_features(cur + 6 * b, reinterpret_cast<const int *>(cur + 18)[b]);
+  double prev_flat = 0.0, prev_hf = 0.0, prev_e = 0.0;
+  if (prev) {
+    const BandFeatures p = band_features(prev + 6 * b, reinterpret_cast<const int *>(prev + 18)[b]);
+    prev_flat = p.flat; prev_hf = p.hf; prev_e = p.energy;
   }
-  return mode_byte;
+  const double ce = c.energy > 1e-10 ? c.energy : 1e-10;     // calculateEnergyChange :172-189
+  const double pe = prev_e > 1e-10 ? prev_e : 1e-10;
+  const double db = 10.0 * js_log10(ce / pe);
+  const double e_change = db > 0 ? db : 0.0;
+  const double flat_c = sqrt(fabs(c.flat - prev_flat));       // calculateTransientScore :197-226
+  const double hf_c = js_log1p(fabs(c.hf - prev_hf) * 10.0) / log1p10;
+  const double e_c = e_change / 30.0 < 1.0 ? e_change / 30.0 : 1.0;
+  const double score = (c.flux + flat_c + hf_c + e_c) / 4.0;
+  if (score_out) *score_out = score;
+  return (score > threshold) ? (b + 1 > 2 ? b + 1 : 2) : 0;   // encoder.js:143
 }
 
+// two work lists for the MDCT stage: all-long units and units with a short band (lists[0], lists[1] = counts, then
+// `units` entries each), and behind them the units the speculative detector could not decide (lists[2]); one atomic per
+// wave and list
+__device__ __forceinline__ void append_by_mode(bool live, int kind, int64_t unit, int64_t units, uint32_t *__restrict__ lists) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const bool mine = live && kind == k;
+    const uint64_t m = __ballot(mine);
+    if (m == 0) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&lists[k], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (mine) lists[4 + (int64_t)k * units + base + __popcll(m & below)] = (uint32_t)unit;
+  }
+}
+
+// SPEC = false: the reference's decision from its 18 sums.  SPEC = true: the interval of c1_detect_bound.h from the
+// binary32 sums; a unit with a band whose interval contains the threshold goes to the third list (k_detect_recheck).
+// `tap` (tests): per unit and band {lo, hi} (SPEC) or {score, score}.
+template <bool SPEC>
 __global__ __launch_bounds__(256) void k_detect_decide(const double *__restrict__ feat_ws, int channels, int64_t frames,
                                                         int halo_frames, const C1DevTables *tables, const C1DevEncOpts *opts,
-                                                        uint8_t *__restrict__ modes, uint32_t *__restrict__ lists) {
+                                                        uint8_t *__restrict__ modes, uint32_t *__restrict__ lists, double *__restrict__ tap) {
   const int64_t unit = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t units = frames * channels;
   const bool live = unit < units;
   int mode_byte = 0;
-  if (live) mode_byte = detect_decide_unit(feat_ws, channels, unit, halo_frames, tables, opts);
-  if (live) modes[unit] = (uint8_t)mode_byte;
-  // two work lists for the MDCT stage: all-long units and units with a short band (lists[0], lists[1] = counts,
-  // then `units` entries each); one atomic per wave and list
-  uint32_t *list_long = lists + 4, *list_mixed = lists + 4 + units;
-  const bool is_long = live && mode_byte == 0, is_mixed = live && mode_byte != 0;
-  const uint64_t ml = __ballot(is_long), mm = __ballot(is_mixed);
-  const int lane = threadIdx.x & 63;
-  const uint64_t below = (1ull << lane) - 1ull;
-  uint32_t base_l = 0, base_m = 0;
-  if (lane == 0) {
-    if (ml) base_l = atomicAdd(&lists[0], (uint32_t)__popcll(ml));
-    if (mm) base_m = atomicAdd(&lists[1], (uint32_t)__popcll(mm));
+  bool certain = true;
+  if (live) {
+    const int64_t f = unit / channels;
+    const bool have_prev = (f - 1 >= -(int64_t)halo_frames);      // else the zero state of a fresh BufferPool
+    const double log1p10 = tables->log1p10, threshold = opts->threshold;
+    if constexpr (SPEC) {
+      const float *cur = reinterpret_cast<const float *>(feat_ws + (unit + channels) * kFeatureDoubles);
+      const float *prev = cur - (int64_t)channels * kFeatureDoubles * 2;
+      for (int b = 0; b < 3; b++) {
+        const C1DetSums sc = c1_det_sums(cur, b);
+        const C1DetSums sp = have_prev ? c1_det_sums(prev, b) : c1_det_zero_sums();
+        const C1DetOwn oc = c1_det_own(sc);
+        C1DetOwn op = oc;
+        if (have_prev) op = c1_det_own(sp);
+        double lo, hi;
+        const int ok = c1_det_score(sc, oc, have_prev ? 1 : 0, sp, op, b == 2 ? 128 : 64, log1p10, &lo, &hi);
+        if (tap) { tap[(unit * 3 + b) * 2] = lo; tap[(unit * 3 + b) * 2 + 1] = hi; }
+        if (ok && lo > threshold) mode_byte |= (b + 1 > 2 ? b + 1 : 2) << (2 * b);
+        else if (!(ok && hi < threshold)) certain = false;
+      }
+    } else {
+      const double *cur = feat_ws + (unit + channels) * kFeatureDoubles;
+      const double *prev = have_prev ? cur - (int64_t)channels * kFeatureDoubles : nullptr;
+      for (int b = 0; b < 3; b++) {
+        double score;
+        mode_byte |= detect_band_mode(cur, prev, b, log1p10, threshold, &score) << (2 * b);
+        if (tap) { tap[(unit * 3 + b) * 2] = score; tap[(unit * 3 + b) * 2 + 1] = score; }
+      }
+    }
   }
-  base_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_l); base_m = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_m);
-  if (is_long) list_long[base_l + __popcll(ml & below)] = (uint32_t)unit;
-  if (is_mixed) list_mixed[base_m + __popcll(mm & below)] = (uint32_t)unit;
+  if (live && certain) modes[unit] = (uint8_t)mode_byte;
+  append_by_mode(live, !certain ? 2 : (mode_byte == 0 ? 0 : 1), unit, units, lists);
 }
 
+// The units the speculative detector left open: the reference's own arithmetic on the stored (exact) band samples of
+// the frame and of its predecessor -- two exact transient FFTs, the 18 sequential sums of each, the scalar features --
+// then the unit joins the MDCT list its block modes call for.  One wave per listed unit.
+struct alignas(16) RecheckLds {
+  alignas(16) float band[512];
+  union alignas(16) {
+    struct { alignas(16) float2 z[576]; } t;
+    struct { alignas(16) double term[4][256]; } tt;
+  } u;
+  alignas(16) double feat_c[kFeatureDoubles];
+  alignas(16) double feat_p[kFeatureDoubles];
+  int mode[4];
+};
+__global__ __launch_bounds__(C1_WAVE, 3) void k_detect_recheck(C1EncodeLaunch L, const float *__restrict__ bands_ws,
+                                                               uint8_t *__restrict__ modes, uint32_t *__restrict__ lists) {
+  __shared__ RecheckLds S;
+  const int lane = threadIdx.x;
+  const int64_t units = L.frames * L.channels;
+  const uint32_t count = lists[2];
+  const uint32_t *__restrict__ list = lists + 4 + 2 * units;
+  const TGeom G = tfft_geometry(lane);
+  const TablesRsrc RT = tables_rsrc(L.tables);
+  TablesPtr T = tables_for_this_frame(L.tables);
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int64_t unit = list[i], slot = unit + L.channels;
+    const bool have_prev = (unit / L.channels - 1 >= -(int64_t)L.halo_frames);
+    float mg[4], pmag[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (have_prev) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + ((slot - L.channels) << 9));
+      reinterpret_cast<float4 *>(S.band)[lane] = p4[lane];
+      reinterpret_cast<float4 *>(S.band)[64 + lane] = p4[64 + lane];
+      __syncthreads();
+      tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
+      exact_sums(S.u.tt.term, G, lane, mg, pmag, S.feat_p);    // its flux sum is not used
+#pragma unroll
+      for (int k = 0; k < 4; k++) pmag[k] = mg[k];
+      __syncthreads();
+    }
+    {
+      const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
+      reinterpret_cast<float4 *>(S.band)[lane] = p4[lane];
+      reinterpret_cast<float4 *>(S.band)[64 + lane] = p4[64 + lane];
+      __syncthreads();
+      tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
+      exact_sums(S.u.tt.term, G, lane, mg, pmag, S.feat_c);
+      __syncthreads();
+    }
+    if (lane < 3) S.mode[lane] = detect_band_mode(S.feat_c, have_prev ? S.feat_p : nullptr, lane, T->log1p10, L.opts->threshold, nullptr);
+    __syncthreads();
+    if (lane == 0) {
+      const int mode_byte = S.mode[0] | (S.mode[1] << 2) | (S.mode[2] << 4);
+      modes[unit] = (uint8_t)mode_byte;
+      const int k = mode_byte == 0 ? 0 : 1;
+      lists[4 + (int64_t)k * units + atomicAdd(&lists[k], 1u)] = (uint32_t)unit;
+    }
+    __syncthreads();
+  }
+}
 
 
 struct alignas(16) MdctLds {
@@ -688,19 +951,51 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
 }  // namespace
 
 void c1k_launch_detect(const C1EncodeLaunch &L0, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
-                       hipStream_t stream) {
-  static const int slots = c1k_wave_slots(k_detect_features);
+                       bool speculative, double *score_tap, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_detect_features<false>);
   C1EncodeLaunch L = L0;
   L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
   const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames, units = L.frames * L.channels;
   (void)hipMemsetAsync(lists_ws, 0, 4 * sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(k_detect_features, dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
-  hipLaunchKernelGGL(k_detect_decide, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, feat_ws, L.channels, L.frames,
-                     L.halo_frames, L.tables, L.opts, modes_ws, lists_ws);
+  const dim3 fgrid((unsigned)(runs * L.channels)), dgrid((unsigned)((units + 255) / 256));
+  if (speculative) {
+    // binary32 transient FFT and sums, the decision where the score's interval allows it, the reference's arithmetic
+    // for the units left open; lists_ws[2] = how many those were
+    hipLaunchKernelGGL((k_detect_features<true>), fgrid, dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
+    hipLaunchKernelGGL((k_detect_decide<true>), dgrid, dim3(256), 0, stream, feat_ws, L.channels, L.frames, L.halo_frames,
+                       L.tables, L.opts, modes_ws, lists_ws, score_tap);
+    hipLaunchKernelGGL(k_detect_recheck, dim3((unsigned)std::min<int64_t>(units, 256 * 12)), dim3(C1_WAVE), 0, stream, L, bands_ws,
+                       modes_ws, lists_ws);
+  } else {
+    hipLaunchKernelGGL((k_detect_features<false>), fgrid, dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
+    hipLaunchKernelGGL((k_detect_decide<false>), dgrid, dim3(256), 0, stream, feat_ws, L.channels, L.frames, L.halo_frames,
+                       L.tables, L.opts, modes_ws, lists_ws, score_tap);
+  }
+  if (!L.coefs) return;                                      // decisions only (score taps)
   // both list kernels size their grids for the whole batch and stop at the device-side count
   const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
   hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
   hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+}
+
+// accuracy of v_log_f32 over a range of binary32 bit patterns (normal, positive): out[0] = max |r - log2 x| / |log2 x| in
+// units of 2^-24 where |log2 x| >= 2^-6, out[1] = max |r - log2 x| elsewhere (both as the bit patterns of non-negative doubles)
+__global__ __launch_bounds__(256) void k_log2f_error(uint32_t first, uint64_t count, unsigned long long *out) {
+  double rel = 0.0, absolute = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float(first + (uint32_t)i);
+    const double exact = log2((double)x), got = (double)__builtin_amdgcn_logf(x);
+    const double err = fabs(got - exact);
+    if (fabs(exact) >= 0.015625) rel = fmax(rel, err / fabs(exact) * 16777216.0); else absolute = fmax(absolute, err);
+  }
+  atomicMax(&out[0], (unsigned long long)__double_as_longlong(rel));
+  atomicMax(&out[1], (unsigned long long)__double_as_longlong(absolute));
+}
+
+void c1k_launch_log2f_error(uint32_t first, uint64_t count, unsigned long long *out, hipStream_t stream) {
+  (void)hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), stream);
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_log2f_error, dim3(256 * 32), dim3(256), 0, stream, first, count, out);
 }
 
 void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream) {

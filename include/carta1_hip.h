@@ -122,6 +122,12 @@ int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int
  * quantize the reference's coefficients in binary32 with the same guard band and pack the few units it cannot certify
  * again in binary64: units packed that way so far and units packed twice (cleared by c1_ctx_speculation_stats(reset)). */
 int c1_ctx_quantization_stats(c1_ctx *ctx, uint64_t *units, uint64_t *repacked);
+/* Transient detection (blockSelectorStage, encoder.js:111-152) runs speculatively too unless speculation is 0: the
+ * transient FFT (transient.js:17-35) in binary32, an interval that provably contains the reference's transient score
+ * (transient.js:197-226), the decision `score > threshold` where the whole interval lies on one side, and the
+ * reference's own arithmetic for the units left open.  Units decided that way so far and units among them that needed
+ * the exact recheck (cleared by c1_ctx_speculation_stats(reset)). */
+int c1_ctx_detection_stats(c1_ctx *ctx, uint64_t *units, uint64_t *rechecked);
 
 /* Decoder arithmetic.  0 (default): the reference's -- binary64 operations, binary32 at every typed-array store --
  * decoded PCM bit-identical to the reference.  1: the same computation in binary32 throughout; the PCM then differs
@@ -229,6 +235,20 @@ int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
  * (fixed_block_modes {-1,-1,-1}).  Either pointer may be NULL. */
 int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                             const c1_encode_options *opts, float *mags, uint8_t *modes);
+
+/* Test tap of the detector's decisions.  scores: frames*channels*3*2 doubles, per unit and band {lo, hi}: with
+ * speculative != 0 the interval the binary32 detector derives for calculateTransientScore (transient.js:197-226), else
+ * the reference's score twice.  modes: frames*channels bytes (after the exact recheck of the open units);
+ * open_units: one uint32 on the device, the number of units whose interval contained the threshold.  Device pointers,
+ * any of them may be NULL. */
+int c1_detect_scores_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                            const c1_encode_options *opts, int speculative, double *scores, uint8_t *modes,
+                            uint32_t *open_units);
+/* Test tap: the device's binary32 log2 (v_log_f32), which the speculative detector's flatness sums use, against
+ * binary64 log2 over the bit patterns [first_bits, first_bits + count) of normal positive numbers.  out (host):
+ * out[0] = max |r - log2 x| / |log2 x| in units of 2^-24 over the x with |log2 x| >= 2^-6, out[1] = max |r - log2 x|
+ * over the others. */
+int c1_log2f_error_device(c1_ctx *ctx, uint32_t first_bits, uint64_t count, double *out);
 
 /* Test tap: Math.log (fn 0), Math.exp (1), Math.log1p (2), Math.log10 (3) as the reference's engine evaluates them and as
  * the detector's kernels use them (transient.js:129, :137, :185, :211; V8 src/base/ieee754.cc = fdlibm, not correctly
