@@ -489,7 +489,7 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
     HIP_TRY(hipMalloc(&ctx->d_cand[p], (size_t)units * kCandidateBytes));
     HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 8 + 4) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&ctx->d_eps[p], (size_t)units * kEpsFloats * sizeof(float)));
-    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units + 4) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units * 2 + 4) * sizeof(uint32_t)));   // [0], [1] counts; redo list, reallocation list
   }
   ctx->ws_units = units;
   return C1_OK;
@@ -678,7 +678,9 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       L.eps = ctx->d_eps[p];
       L.redo_count = ctx->d_redo[p];
       L.redo_list = ctx->d_redo[p] + 4;
-      HIP_TRY(hipMemsetAsync(L.redo_count, 0, sizeof(uint32_t), sA));
+      L.realloc_count = ctx->d_redo[p] + 1;
+      L.realloc_list = ctx->d_redo[p] + 4 + (size_t)ctx->ws_units;
+      HIP_TRY(hipMemsetAsync(L.redo_count, 0, 2 * sizeof(uint32_t), sA));
       { ScopedTiming t(ctx, K_ANALYSIS, sA); c1k_launch_analysis_spec(L, all_short_modes, sA); }
       { ScopedTiming t(ctx, K_ALLOCATE, sA); c1k_launch_allocate(L, sA); }
       { ScopedTiming t(ctx, K_PACK, sA); c1k_launch_pack_spec(L, all_long_modes, sA); }
@@ -688,7 +690,10 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
         R.unit_list = L.redo_list;
         R.unit_count = L.redo_count;
         if (all_long_modes) c1k_launch_analysis_long(R, sA); else c1k_launch_analysis(R, false, sA);
-        c1k_launch_allocate(R, sA);
+        C1EncodeLaunch A = R;
+        A.unit_list = L.realloc_list;
+        A.unit_count = L.realloc_count;
+        c1k_launch_allocate(A, sA);
         c1k_launch_pack(R, all_long_modes, sA);
         c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), L.redo_count, sA);
       }
@@ -718,8 +723,10 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       L.eps = ctx->d_eps[p];
       L.redo_count = ctx->d_redo[p];
       L.redo_list = ctx->d_redo[p] + 4;
+      L.realloc_count = ctx->d_redo[p] + 1;                  // stays empty: with a bound of zero no scale-factor index is open
+      L.realloc_list = ctx->d_redo[p] + 4 + (size_t)ctx->ws_units;
       HIP_TRY(hipMemsetAsync(L.eps, 0, (size_t)n * channels * kEpsFloats * sizeof(float), sB));
-      HIP_TRY(hipMemsetAsync(L.redo_count, 0, sizeof(uint32_t), sB));
+      HIP_TRY(hipMemsetAsync(L.redo_count, 0, 2 * sizeof(uint32_t), sB));
       c1k_launch_pack_spec(L, all_long, sB);
       C1EncodeLaunch R = L;
       R.unit_list = L.redo_list;

@@ -86,6 +86,9 @@ C1_HD C1DetOwn c1_det_own(const C1DetSums s) {
   if (!o.ok) return o;
   const double e = s.elo + s.ehi, rt = sqrt(e);
   if (s.delta == 0.0 && e == 0.0) { o.zero = 1; return o; }          // flat = 0 (no valid bin), hf = 0 (total 0), energy 0
+  // squares of magnitudes below 2^-63 lose bits to underflow in the binary32 sums (at most 128 x 2^-126 in all): with
+  // e >= 2^-90 that is below 2^-29 e; quieter bands are left to the exact kernels
+  if (!(e >= 8.077935669463161e-28)) { o.ok = 0; return o; }
   // | ||c~|| - ||c|| | <= ||c~ - c|| <= Delta
   o.r_lo = rt * (1.0 - C1_DET_SUM) - s.delta;
   if (o.r_lo < 0.0) o.r_lo = 0.0;

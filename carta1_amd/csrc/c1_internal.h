@@ -102,6 +102,8 @@ struct C1EncodeLaunch {
   float *eps;            // frames*channels*kEpsFloats: per-band bound on |binary32 coefficient - reference coefficient|
   uint32_t *redo_list;   // units whose decisions are not certain within the bound (filled by the pack kernel)
   uint32_t *redo_count;
+  uint32_t *realloc_list;   // the listed units whose scale-factor indices were not certain: their allocation is redone too
+  uint32_t *realloc_count;
   // list mode: when unit_list is non-null the kernels process units unit_list[0 .. *unit_count) instead of all
   const uint32_t *unit_list;
   const uint32_t *unit_count;

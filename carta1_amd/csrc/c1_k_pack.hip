@@ -302,10 +302,14 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
     if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
     if constexpr (SPEC) {
       // flag word of the analysis (a scale-factor index was not certain) or any doubtful mantissa -> exact redo
-      const bool redo = __builtin_amdgcn_ballot_w64(doubtful) != 0 || __float_as_int(__shfl(h0.eps, 3)) != 0;
+      const bool sf_open = __float_as_int(__shfl(h0.eps, 3)) != 0;
+      const bool redo = __builtin_amdgcn_ballot_w64(doubtful) != 0 || sf_open;
       if (redo) {
         if (lane == 0) S.redo[n_redo] = (uint32_t)unit;
         n_redo++;
+        // only a unit with an open scale-factor index needs its bits allocated again: the allocation reads nothing but
+        // the indices (bitallocation.js:74-142), and the exact analysis of the others reproduces the ones it ran on
+        if (sf_open && lane == 0) L.realloc_list[atomicAdd(L.realloc_count, 1u)] = (uint32_t)unit;
       }
     }
     wave_sync();
