@@ -275,8 +275,8 @@ static double hf_ratio(const float *c, int n) {
   return tot > 0 ? hi / tot : 0;
 }
 
-/* detectTransient, transient.js:44-55 with its helpers :63-226 */
-int c1o_detect_transient(const float *cur, const float *prev, int n, double threshold) {
+/* calculateSpectralFeatures + calculateTransientScore, transient.js:63-226 */
+double c1o_transient_score(const float *cur, const float *prev, int n) {
   /* calculateSpectralFlux :92-112 */
   double flux = 0, cur_e = 0;
   for (int i = 0; i < n; i++) {
@@ -304,8 +304,12 @@ int c1o_detect_transient(const float *cur, const float *prev, int n, double thre
   double flat_c = sqrt(flat_change);
   double hf_c = c1o_fd_log1p(hf_change * 10) / C1O_LOG1P_10;
   double e_c = e_change / 30 < 1 ? e_change / 30 : 1;
-  double score = (flux + flat_c + hf_c + e_c) / 4;
-  return score > threshold;
+  return (flux + flat_c + hf_c + e_c) / 4;
+}
+
+/* detectTransient, transient.js:44-55 */
+int c1o_detect_transient(const float *cur, const float *prev, int n, double threshold) {
+  return c1o_transient_score(cur, prev, n) > threshold;
 }
 
 /* blockSelectorStage, encoder.js:111-152 */

@@ -75,6 +75,7 @@ void c1o_block_modes(c1o_enc_state *s, const float bands[512], const c1o_options
 void c1o_transient_mags(const float bands[512], float mags[256]);
 /* Math.log (fn 0), exp (1), log1p (2), log10 (3) as V8 evaluates them (c1o_fdlibm.h), on an array */
 void c1o_libm(int fn, const double *in, double *out, long n);
+double c1o_transient_score(const float *cur, const float *prev, int n);   /* transient.js:63-226 */
 int c1o_detect_transient(const float *cur, const float *prev, int n, double threshold);
 void c1o_mdct_frame(c1o_enc_state *s, float bands[512], const int modes[3], float coefs[512]);
 int c1o_find_scale_factor(const float *x, int n);

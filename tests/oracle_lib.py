@@ -61,6 +61,8 @@ def lib():
         _lib.c1o_libm.restype = None
         _lib.c1o_detect_transient.argtypes = [fp, fp, C.c_int, C.c_double]
         _lib.c1o_detect_transient.restype = C.c_int
+        _lib.c1o_transient_score.argtypes = [fp, fp, C.c_int]
+        _lib.c1o_transient_score.restype = C.c_double
         _lib.c1o_mdct_frame.argtypes = [C.POINTER(EncState), fp, ip, fp]
         _lib.c1o_find_scale_factor.argtypes = [fp, C.c_int]
         _lib.c1o_find_scale_factor.restype = C.c_int
