@@ -152,4 +152,4 @@ def test_specials_are_never_decided():
     z = np.zeros(256, np.float32)
     M.detm_record(O._fp(z), O._fp(z), O._fp(np.zeros(3, np.float32)), O._fp(rec))
     assert M.detm_interval(O._fp(rec), O._fp(rec), 0, 2.3978952727983707, C.byref(lo), C.byref(hi)) == 1
-    assert abs(lo.value) < 1e-9 and abs(hi.value) < 1e-9
+    assert abs(lo.value) < 1e-5 and abs(hi.value) < 1e-5
