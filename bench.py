@@ -408,7 +408,9 @@ def main():
         f3 = args.config3_frames
         p3 = generate(f3, 'pink', (3, 4), 0)
         o3 = options_for(None, 1.0)
+        ctx.speculation_stats(reset=True)
         u3, el_e, km_e, _, _ = encode_run(p3, f3, o3.to_c(), 1, 0)
+        det_units, det_open = ctx.detection_stats()
         outp = [torch.empty(f3 * 512, dtype=torch.float32, device=dev) for _ in range(2)]
         optr = [p.data_ptr() for p in outp]
         el_d, km_d = timed(lambda: ctx.decode_device(u3.data_ptr(), 2, f3, optr), 1, 0, ('decode',))
@@ -429,6 +431,7 @@ def main():
                          'encode_ms': el_e * 1e3, 'decode_ms': el_d * 1e3,
                          'encode_kernels_ms': {k: round(v['ms_per_step'], 2) for k, v in km_e.items()},
                          'units_with_a_short_band': short,
+                         'speculative_detector': {'units': det_units, 'left_to_the_exact_recheck': (det_open / det_units) if det_units else None},
                          'parity_subset_frames': nsub, 'units_and_block_modes_equal_oracle': ok_units,
                          'decoded_pcm_rms_vs_oracle': rms, 'decoded_pcm_bit_identical_to_oracle': bool(bits),
                          'mid_stream_slice_with_halo_equals_full_run': mid_ok}

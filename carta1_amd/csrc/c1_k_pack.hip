@@ -143,7 +143,17 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
     uint32_t at = 0;
     if (lane == 0) at = atomicAdd(L.redo_count, (uint32_t)n_redo);
     at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-    if (lane < n_redo) L.redo_list[at + lane] = S.redo[lane];
+    const uint32_t entry = lane < n_redo ? S.redo[lane] : 0u;
+    if (lane < n_redo) L.redo_list[at + lane] = entry & 0x7fffffffu;
+    // bit 31: a scale-factor index of the unit was open, so its bits are allocated again as well (the allocation reads
+    // nothing but the indices, bitallocation.js:74-142; the exact analysis of the others reproduces the ones it ran on)
+    const uint64_t open_mask = __builtin_amdgcn_ballot_w64((entry >> 31) != 0u);
+    if (open_mask != 0) {
+      uint32_t at2 = 0;
+      if (lane == 0) at2 = atomicAdd(L.realloc_count, (uint32_t)__popcll(open_mask));
+      at2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at2);
+      if ((entry >> 31) != 0u) L.realloc_list[at2 + __popcll(open_mask & ((1ull << lane) - 1ull))] = entry & 0x7fffffffu;
+    }
     n_redo = 0;
   };
   // Two register sets (header + coefficients) alternate between "the unit being packed" and "the unit in flight": the
@@ -305,11 +315,8 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
       const bool sf_open = __float_as_int(__shfl(h0.eps, 3)) != 0;
       const bool redo = __builtin_amdgcn_ballot_w64(doubtful) != 0 || sf_open;
       if (redo) {
-        if (lane == 0) S.redo[n_redo] = (uint32_t)unit;
+        if (lane == 0) S.redo[n_redo] = (uint32_t)unit | (sf_open ? 0x80000000u : 0u);
         n_redo++;
-        // only a unit with an open scale-factor index needs its bits allocated again: the allocation reads nothing but
-        // the indices (bitallocation.js:74-142), and the exact analysis of the others reproduces the ones it ran on
-        if (sf_open && lane == 0) L.realloc_list[atomicAdd(L.realloc_count, 1u)] = (uint32_t)unit;
       }
     }
     wave_sync();
