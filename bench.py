@@ -408,7 +408,9 @@ def main():
         f3 = args.config3_frames
         p3 = generate(f3, 'pink', (3, 4), 0)
         o3 = options_for(None, 1.0)
-        ctx.speculation_stats(reset=True)
+        # untimed warm-up on the first chunk: the detection workspace (4.3 GB per 1 M-frame chunk) is allocated on first use
+        wu = encode_run(p3, min(f3, 1 << 20), o3.to_c(), 1, 0)
+        del wu
         u3, el_e, km_e, _, _ = encode_run(p3, f3, o3.to_c(), 1, 0)
         det_units, det_open = ctx.detection_stats()
         outp = [torch.empty(f3 * 512, dtype=torch.float32, device=dev) for _ in range(2)]

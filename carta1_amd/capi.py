@@ -87,6 +87,7 @@ SIGNATURES = {
     'c1_libm_device': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     'c1_detect_scores_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                           C.POINTER(EncodeOptions), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'c1_detect_spec_mags_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     'c1_log2f_error_device': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_double)]),
     'c1_ctx_detection_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     'c1_alloc_bounds_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -241,6 +241,11 @@ class Context:
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts), 1 if speculative else 0,
             C.c_void_p(scores_ptr), C.c_void_p(modes_ptr), C.c_void_p(open_ptr)))
 
+    def detect_spec_mags_device(self, pcm_ptrs, frames, mags_ptr, bounds_ptr, halo_frames=0):
+        """The speculative detector's binary32 magnitude spectra (256 floats per unit) and the bound per band (3 floats per unit)."""
+        capi.check(capi.load().c1_detect_spec_mags_device(
+            self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.c_void_p(mags_ptr), C.c_void_p(bounds_ptr)))
+
     def log2f_error(self, first_bits, count):
         """(max relative error in units of 2^-24, max absolute error near 1) of the device's binary32 log2 over a range of bit patterns"""
         out = (C.c_double * 2)()

@@ -1102,6 +1102,31 @@ int c1_detect_scores_device(c1_ctx *ctx, const float *const *pcm, int channels, 
   return C1_OK;
 }
 
+int c1_detect_spec_mags_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                               float *mags, float *bounds) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_channels(channels))) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
+  if (!pcm || !mags || !bounds) return fail(C1_ERR_ARG, "NULL argument");
+  if (frames > kMaxChunkFrames) return fail(C1_ERR_ARG, "stage taps are not chunked: at most %lld frames per call", (long long)kMaxChunkFrames);
+  if (!ctx->spec_tables_ok) return fail(C1_ERR_ARG, "the installed tables do not admit the speculative paths");
+  for (int c = 0; c < channels; c++)
+    if (!pcm[c] || ((uintptr_t)pcm[c] & 15)) return fail(C1_ERR_ARG, "pcm[%d] must be a 16-byte aligned device pointer", c);
+  if (frames == 0) return C1_OK;
+  if ((rc = ensure_detect_workspace(ctx, frames * channels))) return rc;
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c];
+  L.channels = channels; L.frames = frames; L.halo_frames = halo_frames;
+  L.tables = ctx->d_tables; L.opts = ctx->d_opts;
+  L.mags = mags; L.mag_bounds = bounds;
+  c1k_launch_detect_spec_tap(L, ctx->d_bands[0], ctx->d_feat[0], ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
 int c1_log2f_error_device(c1_ctx *ctx, uint32_t first_bits, uint64_t count, double *out_host) {
   CTX_GUARD(ctx);
   int rc = ctx_bind(ctx);

@@ -97,6 +97,7 @@ struct C1EncodeLaunch {
   uint32_t *sel_list;    // units that kept more than the 52-BFU candidate alive: k_alloc_select picks among their results
   float *bands;      // optional tap (may be null)
   float *mags;       // optional tap of the transient detector's magnitude spectra, frames*channels*256 (64 | 64 | 128)
+  float *mag_bounds; // optional tap (speculative detector only): frames*channels*3, Delta of the three bands
   uint8_t *units;    // frames*channels*212   (may be null for stage taps)
   // speculative binary32 path
   float *eps;            // frames*channels*kEpsFloats: per-band bound on |binary32 coefficient - reference coefficient|
@@ -153,6 +154,7 @@ constexpr int kFeatureWsDoubles = 20;
 // score_tap (tests): units * 3 * 2 doubles {lo, hi} (speculative) or {score, score}.  L.coefs null: decisions only.
 void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
                        bool speculative, double *score_tap, hipStream_t stream);
+void c1k_launch_detect_spec_tap(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, hipStream_t stream);   // L.mags, L.mag_bounds
 void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream);
 void c1k_launch_log2f_error(uint32_t first, uint64_t count, unsigned long long *out, hipStream_t stream);   // out: 2 x u64 on the device
 void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);

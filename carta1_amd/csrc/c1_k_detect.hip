@@ -627,6 +627,11 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
       float delta;
       __builtin_amdgcn_s_setprio(0);
       tfft_spec(S.band, S.u.t.z, G, T, RT, mg, delta);
+      if (L.mags && f >= f0) {                                   // test tap: the binary32 magnitudes and their bound (3 floats per unit)
+#pragma unroll
+        for (int i = 0; i < 4; i++) L.mags[((f * L.channels + ch) << 8) + G.mag + i * G.S] = mg[i];
+        if (L.mag_bounds && G.g == 0) L.mag_bounds[(f * L.channels + ch) * 3 + G.band] = delta;
+      }
       if (emit) spec_sums(G, lane, mg, pmag, delta, reinterpret_cast<float *>(feat_ws + slot * kFeatureDoubles));
     } else {
       tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
@@ -1021,6 +1026,15 @@ void c1k_launch_log2f_error(uint32_t first, uint64_t count, unsigned long long *
   (void)hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), stream);
   if (count == 0) return;
   hipLaunchKernelGGL(k_log2f_error, dim3(256 * 32), dim3(256), 0, stream, first, count, out);
+}
+
+// test tap: the speculative detector's first kernel alone, writing its binary32 magnitudes (L.mags) and bounds (L.mag_bounds)
+void c1k_launch_detect_spec_tap(const C1EncodeLaunch &L0, float *bands_ws, double *feat_ws, hipStream_t stream) {
+  static const int slots = c1k_wave_slots(k_detect_features<true>);
+  C1EncodeLaunch L = L0;
+  L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
+  hipLaunchKernelGGL((k_detect_features<true>), dim3((unsigned)(runs * L.channels)), dim3(C1_WAVE), 0, stream, L, bands_ws, feat_ws);
 }
 
 void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream) {

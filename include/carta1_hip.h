@@ -244,6 +244,11 @@ int c1_detect_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, 
 int c1_detect_scores_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                             const c1_encode_options *opts, int speculative, double *scores, uint8_t *modes,
                             uint32_t *open_units);
+/* Test tap: the speculative detector's binary32 magnitude spectra (mags: frames*channels*256 floats, laid out as
+ * c1_detect_stages_device's) and the bound it claims on the l2 distance of each band's spectrum from the reference's
+ * (bounds: frames*channels*3 floats).  Device pointers. */
+int c1_detect_spec_mags_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                               float *mags, float *bounds);
 /* Test tap: the device's binary32 log2 (v_log_f32), which the speculative detector's flatness sums use, against
  * binary64 log2 over the bit patterns [first_bits, first_bits + count) of normal positive numbers.  out (host):
  * out[0] = max |r - log2 x| / |log2 x| in units of 2^-24 over the x with |log2 x| >= 2^-6, out[1] = max |r - log2 x|

@@ -73,6 +73,45 @@ def test_device_log2_meets_the_error_model(ctx):
     assert worst_abs <= 2.0 ** -22, worst_abs     # elsewhere (x near 1)
 
 
+WORST = {}
+
+
+@pytest.mark.parametrize('name,pcm', ALL, ids=[s[0] for s in ALL])
+def test_magnitudes_lie_within_their_bound(ctx, name, pcm):
+    """|| binary32 magnitudes - the exact kernel's (= the reference's Float32) magnitudes ||_2 <= Delta, per band and frame:
+    the K of c1_detect_bound.h at work.  The worst ratio seen is printed (DESIGN.md 3c quotes it)."""
+    import torch
+    import carta1_amd as c1
+    other = O.gen_white(8, len(pcm))
+    frames = len(pcm) // 512
+    dev = [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in (pcm, other)]
+    ptrs = [d.data_ptr() for d in dev]
+    units = frames * 2
+    exact = torch.zeros(units * 256, dtype=torch.float32, device='cuda')
+    spec = torch.zeros(units * 256, dtype=torch.float32, device='cuda')
+    bounds = torch.zeros(units * 3, dtype=torch.float32, device='cuda')
+    torch.cuda.synchronize()
+    ctx.detect_stages_device(ptrs, frames, exact.data_ptr(), 0, c1.EncoderOptions({}))
+    ctx.detect_spec_mags_device(ptrs, frames, spec.data_ptr(), bounds.data_ptr())
+    ctx.synchronize()
+    e = exact.cpu().numpy().reshape(units, 256).astype(np.float64)
+    g = spec.cpu().numpy().reshape(units, 256).astype(np.float64)
+    b = bounds.cpu().numpy().reshape(units, 3).astype(np.float64)
+    worst = 0.0
+    for k, (lo, hi) in enumerate(((0, 64), (64, 128), (128, 256))):
+        dist = np.sqrt(np.sum((g[:, lo:hi] - e[:, lo:hi]) ** 2, axis=1))
+        fin = np.isfinite(dist) & np.isfinite(b[:, k])
+        assert (dist[fin] <= b[fin, k]).all(), (name, k, np.argwhere(fin & (dist > b[:, k]))[:4])
+        assert (~np.isfinite(b[~np.isfinite(dist), k])).all()          # a non-finite spectrum never carries a finite bound
+        pos = fin & (b[:, k] > 0)
+        if pos.any():
+            worst = max(worst, float(np.max(dist[pos] / b[pos, k])))
+        assert (dist[fin & (b[:, k] == 0)] == 0).all()                   # Delta = 0 only for an all-zero band, whose magnitudes are exact
+    WORST[name] = worst
+    print('worst ||error|| / Delta for %s: %.4f' % (name, worst))
+    assert worst < 0.5, (name, worst)                                    # the bound is a worst case over rounding directions; a sanity margin
+
+
 @pytest.mark.parametrize('name,pcm', ALL, ids=[s[0] for s in ALL])
 def test_interval_contains_the_reference_score(ctx, name, pcm):
     exact, modes_exact, _ = scores(ctx, pcm, False)
