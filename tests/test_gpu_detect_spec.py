@@ -143,6 +143,16 @@ def test_threshold_inside_the_score_distribution(ctx, name):
             assert opened > 0                     # a score equal or next to the threshold is never decided speculatively
 
 
+@pytest.mark.parametrize('thr', [0.01, 0.05, 2.0])
+def test_threshold_at_the_ends_of_its_range(ctx, thr):
+    """options.js:101-105 allows 0.01 .. 2: nearly everything / nearly nothing is a transient"""
+    for name in ('pink_bursts', 'castanets', 'sine_1k', 'silence', 'tiny'):
+        pcm = dict(ALL)[name]
+        _, modes_exact, _ = scores(ctx, pcm, False, threshold=thr)
+        _, modes_spec, _ = scores(ctx, pcm, True, threshold=thr)
+        assert np.array_equal(modes_spec, modes_exact), (name, thr)
+
+
 def test_halo_frames_and_stream_start(ctx):
     pcm = dict(ALL)['castanets']
     for halo in (0, 1, 2):
