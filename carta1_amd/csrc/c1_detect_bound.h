@@ -35,13 +35,14 @@
 #define C1_DET_ROWS 4                /* band 0 | band 1 | band 2 lanes 32..47 | band 2 lanes 48..63 */
 
 // The interval itself is evaluated in binary32 with outward slack (one lane per sound unit evaluates six of these per
-// call; in binary64 that was 0.8 ms per 2 M units, a fifth of the detector).  Every binary32 operation used here -- add,
-// multiply, divide, square root, expf, log2f, log1pf, on the device and in the host's libm alike -- returns its result
-// within 2^-22 relative (a few ulp); C1_UP / C1_DN move a freshly computed upper / lower endpoint outwards by 2^-21
-// relative and 1e-37 absolute (underflow), which covers that and their own two roundings.  All formulas are monotone in
-// every endpoint they read, so lower endpoints stay below and upper endpoints above what exact arithmetic would give.
-#define C1_UP(x) ((x) + fabsf(x) * 4.76837158203125e-07f + 1e-37f)
-#define C1_DN(x) ((x) - fabsf(x) * 4.76837158203125e-07f - 1e-37f)
+// call; in binary64 that was a third of the decision kernel).  Every binary32 operation used here -- add, multiply,
+// divide and square root (correctly rounded), expf, log2f, log1pf (within 3 ulp = 3.6e-7 relative by the OpenCL bounds
+// the device library is built to, 1 ulp in the host's libm) -- returns its result within 2^-21 relative; C1_UP / C1_DN
+// move a freshly computed upper / lower endpoint outwards by 2^-20 relative and 1e-37 absolute (underflow), which
+// covers that and their own two roundings.  All formulas are monotone in every endpoint they read, so lower endpoints
+// stay below and upper endpoints above what exact arithmetic would give.
+#define C1_UP(x) ((x) + fabsf(x) * 9.5367431640625e-07f + 1e-37f)
+#define C1_DN(x) ((x) - fabsf(x) * 9.5367431640625e-07f - 1e-37f)
 #define C1_FIN(x) ((x) < 3.0e38f && (x) > -3.0e38f)     /* finite and not NaN */
 
 // sums of one band of one frame (all over the band's bins k; "valid" = magnitude certainly > 1e-10)
@@ -114,8 +115,8 @@ C1_HD C1DetOwn c1_det_own(const C1DetSums s) {
     const float ln2 = 0.6931472f;
     const float el = C1_UP(C1_UP(C1_UP(C1_UP(s.delta * sqrtf(s.sinv2)) * 1.001f) + 1.5e-06f * s.sabs) / s.nv) + 1.7e-07f;
     if (!(el < 0.5f)) { o.ok = 0; return o; }
-    const float ml = ln2 * s.slog / s.nv;                // within (|ml| + 1) 2^-21 of the exact mean, and so is exp of it, relatively
-    const float gm = expf(ml), ge = (fabsf(ml) + 2.0f) * 4.76837158203125e-07f;
+    const float ml = ln2 * s.slog / s.nv;                // within |ml| 2^-21 of the exact mean; expf adds 3 ulp: (|ml| + 2) 2^-20 covers both
+    const float gm = expf(ml), ge = (fabsf(ml) + 2.0f) * 9.5367431640625e-07f;
     const float gm_lo = C1_DN(gm * C1_DN(1.0f - el - ge));             // exp(-x) >= 1 - x
     const float gm_hi = C1_UP(gm * C1_UP(1.0f + el + el * el + ge));   // exp(x) <= 1 + x + x^2 on [0, 1]
     // |sum c~_k - sum c_k| <= sqrt(nv) Delta
