@@ -222,6 +222,7 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
   // and two FMAs give the correctly rounded quotient (Markstein); rather than rely on the theorem's side
   // conditions, compare against the division for every input the decoder can meet with this table.
   d->dq_fast = 1;
+  d->dq_step = 1;
   for (int wl = 1; wl < 16 && d->dq_fast; wl++) {
     const int bits = wl + 1;
     const double range = (double)((1 << (bits - 1)) - 1), y = 1.0 / range;
@@ -232,9 +233,13 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
         const double a = (double)q * sf;
         const double q0 = a * y, r = std::fma(-q0, range, a), fast = std::fma(r, y, q0), exact = a / range;
         if (!(fast == exact) || std::signbit(fast) != std::signbit(exact)) { d->dq_fast = 0; break; }
+        // after the store to the Float32 array even the plain product with one rounded step per BFU is the same value
+        const float f_exact = (float)exact, f_step = (float)((double)q * (sf * y));
+        if (!(f_step == f_exact) || std::signbit(f_step) != std::signbit(f_exact)) d->dq_step = 0;
       }
     }
   }
+  if (!d->dq_fast || getenv("C1_NO_DQ_STEP")) d->dq_step = 0;      // the variable: tests of the reciprocal form, which the step form shadows
   build_spec_tables(t, d);
 }
 
@@ -815,7 +820,7 @@ int c1_table_fast_paths(int *scale_factor_bits, int *dequant_reciprocal) {
   std::unique_ptr<C1DevTables> d(new C1DevTables);
   build_device_tables(t, d.get());
   if (scale_factor_bits) *scale_factor_bits = d->sf_fast;
-  if (dequant_reciprocal) *dequant_reciprocal = d->dq_fast;
+  if (dequant_reciprocal) *dequant_reciprocal = d->dq_fast + d->dq_step;
   return C1_OK;
 }
 

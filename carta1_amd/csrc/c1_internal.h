@@ -31,6 +31,9 @@ struct C1DevTables {
   // (Markstein): dq_fast = 1 when the host has checked it against the division for every (bits, sfi, q) of
   // the installed table (8.3 M cases), else the kernel divides
   int32_t dq_fast;
+  // stronger: Float32((q * SF) / range) == Float32(q * RN(SF * y)) for every (bits, sfi, q) of the installed table (the
+  // host checks all of them): one product per BFU, then a conversion, a multiply and a conversion per coefficient
+  int32_t dq_step;
   double inv_range[16];      // RN(1 / (2^(wl) - 1)) by word-length index wl = 1..15
   // ---- binary32 tables of the speculative path (c1_k_spec.hip): roundings of the tables above ----
   float tap32[24];           // QMF_EVEN (binary32 in the reference already)

@@ -45,6 +45,7 @@ struct alignas(16) DecodeLds {
   uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
   R sf_tab[64];         // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
   R inv_tab[16];        // coefficient would cost a cache round trip each)
+  R step[52];           // per BFU of the unit: SF * RN(1 / range) (binary64 decoder with dq_step)
   union alignas(16) {
     float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
     float band[512];    // reconstructed bands: born at the overlap-add
@@ -270,7 +271,10 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
     }
     const int mybits = wl_bits(wl) * my_size;
     const int scan = wave_inclusive_scan(mybits);
-    if (lane < 52) S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
+    if (lane < 52) {
+      S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
+      if constexpr (!F32) S.step[lane] = S.sf_tab[sfi] * S.inv_tab[wl_bits(wl) > 0 ? wl_bits(wl) - 1 : 0];   // SF * RN(1 / range): see dq_step
+    }
     __syncthreads();
     // ---------------- dequantizationStage (decoder.js:52-98) ----------------
     const bool all_long = (m0 | m1 | m2) == 0;
@@ -288,12 +292,16 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
       if (sf != 0) {
         if constexpr (F32) v = ((float)q * S.sf_tab[sf]) * S.inv_tab[bits - 1];
         else {
+        if (T->dq_step) {
+          v = f32((double)q * S.step[sb]);                      // == Float32((q * SF) / range) for every input (checked on the host)
+        } else {
         const double a = (double)q * S.sf_tab[sf];
         if (T->dq_fast) {
           const double y = S.inv_tab[bits - 1], q0 = a * y;
           v = f32(__builtin_fma(__builtin_fma(-q0, (double)range, a), y, q0));                  // == a / range (checked on the host)
         } else {
           v = f32(a / (double)range);
+        }
         }
         }
       }

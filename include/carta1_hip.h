@@ -93,7 +93,9 @@ int c1_default_encode_options(c1_encode_options *out);
  * tables currently installed.  Both are verified on the host against the plain formulation for the whole input
  * domain when tables are installed, and the kernels fall back to it when a check fails:
  *  scale_factor_bits  findScaleFactor (bitallocation.js:290-299) from the binary32 bit pattern
- *  dequant_reciprocal dequantize's (q * SF) / range (quantization.js:65-78) as multiply + two FMAs */
+ *  dequant_reciprocal dequantize's (q * SF) / range (quantization.js:65-78): 1 = as multiply + two FMAs with RN(1 / range);
+ *                     2 = moreover, after the store to the Float32 array, equal to q * RN(SF * RN(1 / range)) for every
+ *                     (word length, scale factor, q): one product per BFU and one per coefficient */
 int c1_table_fast_paths(int *scale_factor_bits, int *dequant_reciprocal);
 
 /* ---- contexts ------------------------------------------------------------------------- */

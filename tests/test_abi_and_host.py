@@ -154,7 +154,7 @@ def test_table_dependent_shortcuts_are_verified_for_the_default_tables():
     lib = capi.load()
     a, b = C.c_int(-1), C.c_int(-1)
     assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0
-    assert (a.value, b.value) == (1, 1)
+    assert (a.value, b.value) == (1, 2)
     t = capi.Tables()
     assert lib.c1_get_default_tables(C.byref(t)) == 0
     t.scale_factors[10] *= 1.0000001            # no longer 2^(i/3 - 21): the bit-pattern form must be refused
@@ -164,7 +164,12 @@ def test_table_dependent_shortcuts_are_verified_for_the_default_tables():
         assert a.value == 0
     finally:
         lib.c1_set_tables(None)
-    assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (1, 1)
+    assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (1, 2)
+    os.environ['C1_NO_DQ_STEP'] = '1'
+    try:
+        assert lib.c1_table_fast_paths(C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (1, 1)
+    finally:
+        del os.environ['C1_NO_DQ_STEP']
 
 
 def test_page_locked_allocation_needs_a_device():

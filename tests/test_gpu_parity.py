@@ -207,6 +207,32 @@ def test_decode_arbitrary_bytes_matches_oracle(ctx):
         assert np.array_equal(got[c].view(np.uint32), want[c].view(np.uint32))
 
 
+def test_decode_without_the_step_form_of_dequantize():
+    """the reciprocal + two-FMA form of dequantize (quantization.js:65-78) that the per-BFU step form shadows with the
+    reference's tables: same PCM, bit for bit, on arbitrary units and on an encoded stream"""
+    import carta1_amd as c1
+    os.environ['C1_NO_DQ_STEP'] = '1'
+    try:
+        c = c1.Context(0)                       # tables are built when the context is created
+    finally:
+        del os.environ['C1_NO_DQ_STEP']
+    try:
+        rng = np.random.RandomState(78)
+        units = rng.randint(0, 256, size=(300 * 2, 212)).astype(np.uint8)
+        want, _ = O.decode_stream(units, 2)
+        got = c.decode(units, 2)
+        for ch in range(2):
+            assert np.array_equal(got[ch].view(np.uint32), want[ch].view(np.uint32))
+        chs = [O.gen_pinkT(3, 200 * 512), O.gen_white(2, 200 * 512)]
+        enc, _ = O.encode_stream(chs)
+        want, _ = O.decode_stream(enc, 2)
+        got = c.decode(enc, 2)
+        for ch in range(2):
+            assert np.array_equal(got[ch].view(np.uint32), want[ch].view(np.uint32))
+    finally:
+        c.close()
+
+
 def test_edge_cases_against_reference(ctx):
     import carta1_amd as c1
     e = json.load(open(os.path.join(G, 'aea_edge_cases.json')))['cases']
