@@ -53,6 +53,7 @@ SIGNATURES = {
     'c1_ctx_set_speculation': (C.c_int, [C.c_void_p, C.c_int]),
     'c1_ctx_set_decode_precision': (C.c_int, [C.c_void_p, C.c_int]),
     'c1_ctx_speculation_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    'c1_ctx_speculation_deferred': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     'c1_ctx_quantization_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     'c1_encode_device': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int,
                                    C.POINTER(EncodeOptions), C.c_void_p]),

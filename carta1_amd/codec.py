@@ -110,7 +110,8 @@ class Context:
         return ms.value, n.value
 
     def set_speculation(self, mode):
-        """0 = exact kernels only, 1 = adaptive (default), 2 = always speculate (include/carta1_hip.h)."""
+        """0 = exact kernels only, 1 = material-local (default: runs the predictor rejects go to the exact kernels),
+        2 = always speculate (include/carta1_hip.h)."""
         capi.check(capi.load().c1_ctx_set_speculation(self._h, int(mode)))
 
     def set_decode_precision(self, binary32):
@@ -122,6 +123,12 @@ class Context:
         u, r = C.c_uint64(0), C.c_uint64(0)
         capi.check(capi.load().c1_ctx_speculation_stats(self._h, C.byref(u), C.byref(r), 1 if reset else 0))
         return u.value, r.value
+
+    def speculation_deferred(self):
+        """units whose runs the speculative analysis handed to the exact kernels (material-local mode)"""
+        u = C.c_uint64(0)
+        capi.check(capi.load().c1_ctx_speculation_deferred(self._h, C.byref(u)))
+        return int(u.value)
 
     # ---- host-resident batches ------------------------------------------------------------------
     def quantization_stats(self):

@@ -353,7 +353,8 @@ int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
   return C1_OK;
 }
 
-constexpr int64_t kSpecProbeFrames = 32768;            // adaptive speculation: frames speculated at the start of every 16th call of a stream in exact mode
+constexpr int kTotals = 8;                             // running totals of a context (c1_ctx::d_spec_totals)
+constexpr int kListHead = 8;                           // uint32 counters in front of the speculative path's lists
 constexpr int64_t kMaxChunkFrames = (int64_t)1 << 27;   // x 2 channels = 2^28 units per chunk < 2^29
 
 struct Timing {
@@ -387,13 +388,18 @@ struct c1_ctx {
   // speculative binary32 path: per-unit error bounds, redo list ([0] = count, list from [4]), running totals
   float *d_eps[2] = {nullptr, nullptr};
   uint32_t *d_redo[2] = {nullptr, nullptr};
-  unsigned long long *d_spec_totals = nullptr;   // [0] units encoded speculatively, [1] units redone exactly
-  int spec_mode = 1;                             // 0 exact only, 1 adaptive (default), 2 always speculate
+  // running totals on the device: [0] units that stayed with the speculative analysis, [1] units among them redone exactly,
+  // [2] units of exact coefficients quantized in binary32, [3] units among them packed again, [4] units the speculative
+  // detector decided, [5] units among them rechecked, [6] units the speculative analysis handed to the exact kernels.
+  // h_totals is a page-locked mirror the totals kernel refreshes: the encode entry reads it WITHOUT synchronising
+  // (the adaptive switches below are heuristics; a value that lags by a call or two serves them as well)
+  unsigned long long *d_spec_totals = nullptr;
+  volatile unsigned long long *h_totals = nullptr;
+  unsigned long long *h_totals_dev = nullptr;    // device address of h_totals
+  int spec_mode = 1;                             // 0 exact only, 1 material-local (default), 2 always speculate
+  float spec_defer = 1.0f;                       // mode 1: predicted open decisions per unit past which a run goes to the exact kernels
   bool decode_binary32 = false;                  // c1_ctx_set_decode_precision: opt-in binary32 decoder
   bool spec_tables_ok = false;
-  double spec_last_fraction = 0.0;               // redo fraction seen by the previous speculative call (adaptive mode)
-  int spec_exact_calls = 0;                      // calls sent down the exact path since that observation
-  unsigned long long spec_seen[2] = {0, 0};      // totals at the last observation
   // binary32 quantization of exact coefficients (the exact paths' packing): the same bookkeeping, d_spec_totals[2..3]
   double q32_last_fraction = 0.0;
   int q32_off_calls = 0;
@@ -494,10 +500,26 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
     HIP_TRY(hipMalloc(&ctx->d_cand[p], (size_t)units * kCandidateBytes));
     HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 8 + 4) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&ctx->d_eps[p], (size_t)units * kEpsFloats * sizeof(float)));
-    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units * 2 + 4) * sizeof(uint32_t)));   // [0], [1] counts; redo list, reallocation list
+    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units * 4 + kListHead) * sizeof(uint32_t)));   // counts, then four lists (bind_lists)
   }
   ctx->ws_units = units;
   return C1_OK;
+}
+
+// the lists of the speculative path in workspace half p: counts at [0, kListHead), then the redo, reallocation,
+// re-analysis and deferred-run lists, ws_units entries each
+void bind_lists(c1_ctx *ctx, int p, C1EncodeLaunch *L) {
+  uint32_t *base = ctx->d_redo[p];
+  const size_t u = (size_t)ctx->ws_units;
+  L->redo_count = base;
+  L->realloc_count = base + 1;
+  L->reana_count = base + 2;
+  L->redo_list = base + kListHead;
+  L->realloc_list = base + kListHead + u;
+  L->reana_list = base + kListHead + 2 * u;
+}
+void bind_defer(c1_ctx *ctx, int p, C1EncodeLaunch *L) {
+  L->defer_list = ctx->d_redo[p] + kListHead + 3 * (size_t)ctx->ws_units;   // one slot per run and channel (<= units)
 }
 
 int ensure_io(c1_ctx *ctx, size_t bytes) {
@@ -611,41 +633,27 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   bool quantize32 = !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;   // exact coefficients, binary32 quantization with the guard (below)
   static const bool det_spec_env_off = getenv("C1_DETECT_SPEC") && atoi(getenv("C1_DETECT_SPEC")) == 0;   // experiments: exact detector, the rest as usual
   bool detect_spec = detect && !taps && ctx->spec_tables_ok && ctx->spec_mode != 0 && !det_spec_env_off;   // binary32 transient detector with a score interval
-  int64_t probe_frames = 0;
-  if (quantize32 && ctx->spec_mode == 1) {
-    // adaptive: look at what the previous calls had to redo (their kernels have normally finished by now)
+  if (quantize32 && ctx->spec_mode == 1 && ctx->h_totals) {
+    // adaptive switches of the exact paths: what the calls that have FINISHED so far had to repeat.  Read from the
+    // page-locked mirror without synchronising -- this entry point stays asynchronous on the context's stream.
     unsigned long long tot[6];
-    if (hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-        hipStreamSynchronize(ctx->stream) == hipSuccess) {
-      const unsigned long long du = tot[0] - ctx->spec_seen[0], dr = tot[1] - ctx->spec_seen[1];
-      if (du > 0) { ctx->spec_last_fraction = (double)dr / (double)du; ctx->spec_exact_calls = 0; }
-      ctx->spec_seen[0] = tot[0]; ctx->spec_seen[1] = tot[1];
-      const unsigned long long qu = tot[2] - ctx->q32_seen[0], qr = tot[3] - ctx->q32_seen[1];
-      if (qu > 0) { ctx->q32_last_fraction = (double)qr / (double)qu; ctx->q32_off_calls = 0; }
-      ctx->q32_seen[0] = tot[2]; ctx->q32_seen[1] = tot[3];
-      const unsigned long long tu = tot[4] - ctx->det_seen[0], tr = tot[5] - ctx->det_seen[1];
-      if (tu > 0) { ctx->det_last_fraction = (double)tr / (double)tu; ctx->det_off_calls = 0; }
-      ctx->det_seen[0] = tot[4]; ctx->det_seen[1] = tot[5];
-    }
+    for (int i = 0; i < 6; i++) tot[i] = ctx->h_totals[i];
+    const unsigned long long qu = tot[2] - ctx->q32_seen[0], qr = tot[3] - ctx->q32_seen[1];
+    if (qu > 0 && tot[2] >= ctx->q32_seen[0]) { ctx->q32_last_fraction = (double)qr / (double)qu; ctx->q32_off_calls = 0; }
+    ctx->q32_seen[0] = tot[2]; ctx->q32_seen[1] = tot[3];
+    const unsigned long long tu = tot[4] - ctx->det_seen[0], tr = tot[5] - ctx->det_seen[1];
+    if (tu > 0 && tot[4] >= ctx->det_seen[0]) { ctx->det_last_fraction = (double)tr / (double)tu; ctx->det_off_calls = 0; }
+    ctx->det_seen[0] = tot[4]; ctx->det_seen[1] = tot[5];
     // A listed unit costs two exact transient FFTs where the exact detector spends one per unit: past a fifth of the
     // units left open the speculative detector is a loss, and such a stream keeps the exact one (probed every 16th call).
     if (detect_spec && ctx->det_last_fraction > 0.20 && ctx->det_off_calls < 15) { detect_spec = false; ctx->det_off_calls++; }
     // Material coded with long word lengths (tones: 12-16 bits) leaves binary32 too few fraction bits to certify a
     // truncation; packing twice is then a loss, so such streams keep the binary64 packing, probed again every 16th call.
-    if (ctx->q32_last_fraction > 0.10 && ctx->q32_off_calls < 15) { quantize32 = false; ctx->q32_off_calls++; }
+    // (Only where the whole call is exact: a speculative call quantizes the runs it hands to the exact kernels in
+    // binary32 too, unit by unit.)
+    if (!speculate && ctx->q32_last_fraction > 0.10 && ctx->q32_off_calls < 15) { quantize32 = false; ctx->q32_off_calls++; }
   }
-  if (speculate && ctx->spec_mode == 1) {
-    // Signals whose spectrum is far from flat (tones) fail the guard band of the speculative analysis for most units;
-    // then the speculative pass is wasted work, so such streams go straight to the exact kernels.
-    if (ctx->spec_last_fraction > 0.30) {
-      // exact kernels for this call; every 16th call a slice at its start is speculated to see whether the material
-      // has changed (a whole speculative call on tonal material costs three times an exact one)
-      if (ctx->spec_exact_calls < 15) ctx->spec_exact_calls++;
-      else probe_frames = std::min<int64_t>(frames, kSpecProbeFrames);
-      speculate = false;
-    }
-  }
-  const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate && probe_frames == 0;
+  const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate;
   hipStream_t sA = piped ? ctx->s_ana : ctx->stream, sB = piped ? ctx->s_rest : ctx->stream;
   if (piped) {
     HIP_TRY(hipEventRecord(ctx->ev_in, ctx->stream));
@@ -654,8 +662,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   }
   int64_t index = 0;
   for (int64_t f0 = 0, n = 0; f0 < frames; f0 += n, ++index) {
-    const bool probing = probe_frames > 0 && f0 == 0;
-    n = taps ? frames : (probing ? probe_frames : std::min(chunk, frames - f0));
+    n = taps ? frames : std::min(chunk, frames - f0);
     const int p = piped ? (int)(index & 1) : 0;
     C1EncodeLaunch L;
     memset(&L, 0, sizeof L);
@@ -676,31 +683,48 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     L.units = units ? units + f0 * channels * C1_UNIT_BYTES : nullptr;
     const bool all_long = all_long_modes;
     if (piped && index >= 2) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_free[p], 0));   // workspace half p is free again
-    if (speculate || probing) {
+    if (speculate) {
       // Speculative pass in binary32 (c1_k_spec.hip): coefficients with a proven error bound; allocation works on the
       // scale-factor indices; the packing kernel accepts a unit only when every decision is certain within the bound
       // and lists the others.  Then the exact kernels redo the listed units in place.
+      // Material-local: every 16 frames of a run the speculative kernel estimates from the scale-factor indices and its
+      // bound how many decisions of a unit will stay open; past spec_defer it hands the rest of the run to the exact
+      // kernels (run list), whose units are then quantized in binary32 behind a bound of zero like the exact paths'.
       L.eps = ctx->d_eps[p];
-      L.redo_count = ctx->d_redo[p];
-      L.redo_list = ctx->d_redo[p] + 4;
-      L.realloc_count = ctx->d_redo[p] + 1;
-      L.realloc_list = ctx->d_redo[p] + 4 + (size_t)ctx->ws_units;
-      HIP_TRY(hipMemsetAsync(L.redo_count, 0, 2 * sizeof(uint32_t), sA));
-      { ScopedTiming t(ctx, K_ANALYSIS, sA); c1k_launch_analysis_spec(L, all_short_modes, sA); }
+      bind_lists(ctx, p, &L);
+      if (ctx->spec_mode == 1) { bind_defer(ctx, p, &L); L.spec_defer = ctx->spec_defer; }
+      HIP_TRY(hipMemsetAsync(ctx->d_redo[p], 0, kListHead * sizeof(uint32_t), sA));
+      {
+        ScopedTiming t(ctx, K_ANALYSIS, sA);
+        c1k_launch_analysis_spec(L, all_short_modes, sA);
+        if (L.defer_list) {
+          C1EncodeLaunch D = L;
+          uint32_t *dense = ctx->d_redo[p] + kListHead + 2 * (size_t)ctx->ws_units;   // the re-analysis list's space: that list is filled
+          c1k_launch_defer_compact(L, dense, ctx->d_redo[p] + 3, sA);                 // by the packing kernel, after this pass is done
+          D.unit_list = dense;
+          D.unit_count = ctx->d_redo[p] + 3;
+          D.list_runs = 1;
+          D.defer_list = nullptr;
+          if (all_long_modes) c1k_launch_analysis_long(D, sA); else c1k_launch_analysis(D, false, sA);
+        }
+      }
       { ScopedTiming t(ctx, K_ALLOCATE, sA); c1k_launch_allocate(L, sA); }
       { ScopedTiming t(ctx, K_PACK, sA); c1k_launch_pack_spec(L, all_long_modes, sA); }
       {
         ScopedTiming t(ctx, K_REDO, sA);
         C1EncodeLaunch R = L;
-        R.unit_list = L.redo_list;
-        R.unit_count = L.redo_count;
+        R.defer_list = nullptr;
+        R.unit_list = L.reana_list;
+        R.unit_count = L.reana_count;
         if (all_long_modes) c1k_launch_analysis_long(R, sA); else c1k_launch_analysis(R, false, sA);
         C1EncodeLaunch A = R;
         A.unit_list = L.realloc_list;
         A.unit_count = L.realloc_count;
         c1k_launch_allocate(A, sA);
+        R.unit_list = L.redo_list;
+        R.unit_count = L.redo_count;
         c1k_launch_pack(R, all_long_modes, sA);
-        c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), L.redo_count, sA);
+        c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), ctx->d_redo[p], 0, sA);
       }
       continue;
     }
@@ -709,7 +733,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       if (all_long) c1k_launch_analysis_long(L, sA);
       else if (detect) {
         c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], ctx->d_lists[p], detect_spec, nullptr, sA);
-        if (detect_spec) c1k_launch_spec_totals(ctx->d_spec_totals + 4, (uint64_t)(n * channels), ctx->d_lists[p] + 2, sA);
+        if (detect_spec) c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), ctx->d_lists[p] + 2, 2, sA);
         if (L.bands) HIP_TRY(hipMemcpyAsync(L.bands, ctx->d_bands[p] + (size_t)channels * 512, (size_t)n * channels * 512 * sizeof(float),
                                             hipMemcpyDeviceToDevice, sA));
       } else c1k_launch_analysis(L, false, sA);
@@ -726,18 +750,16 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       // two) truncates differently; the few units it lists (and anything not finite) are packed again by the exact kernel.
       ScopedTiming t(ctx, K_PACK, sB);
       L.eps = ctx->d_eps[p];
-      L.redo_count = ctx->d_redo[p];
-      L.redo_list = ctx->d_redo[p] + 4;
-      L.realloc_count = ctx->d_redo[p] + 1;                  // stays empty: with a bound of zero no scale-factor index is open
-      L.realloc_list = ctx->d_redo[p] + 4 + (size_t)ctx->ws_units;
+      bind_lists(ctx, p, &L);                                  // the reallocation and re-analysis lists stay empty: with bounds of zero no
+                                                               // scale-factor index is open and every coefficient is the exact kernels'
       HIP_TRY(hipMemsetAsync(L.eps, 0, (size_t)n * channels * kEpsFloats * sizeof(float), sB));
-      HIP_TRY(hipMemsetAsync(L.redo_count, 0, 2 * sizeof(uint32_t), sB));
+      HIP_TRY(hipMemsetAsync(ctx->d_redo[p], 0, kListHead * sizeof(uint32_t), sB));
       c1k_launch_pack_spec(L, all_long, sB);
       C1EncodeLaunch R = L;
       R.unit_list = L.redo_list;
       R.unit_count = L.redo_count;
       c1k_launch_pack(R, all_long, sB);
-      c1k_launch_spec_totals(ctx->d_spec_totals + 2, (uint64_t)(n * channels), L.redo_count, sB);
+      c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), L.redo_count, 1, sB);
     } else if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, all_long, sB); }
     if (piped) HIP_TRY(hipEventRecord(ctx->ev_free[p], sB));
   }
@@ -866,13 +888,25 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   hipError_t me = hipMalloc(&ctx->d_tables, sizeof(C1DevTables));
   if (me == hipSuccess) me = hipMalloc(&ctx->d_opts, sizeof(C1DevEncOpts));
   if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
-  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, 6 * sizeof(unsigned long long));
-  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, 6 * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, kTotals * sizeof(unsigned long long));
+  if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, kTotals * sizeof(unsigned long long));
+  if (me == hipSuccess) {
+    void *hp = nullptr, *dp = nullptr;
+    me = hipHostMalloc(&hp, kTotals * sizeof(unsigned long long), hipHostMallocMapped);
+    if (me == hipSuccess) {
+      memset(hp, 0, kTotals * sizeof(unsigned long long));
+      ctx->h_totals = static_cast<volatile unsigned long long *>(hp);
+      me = hipHostGetDevicePointer(&dp, hp, 0);
+      ctx->h_totals_dev = static_cast<unsigned long long *>(dp);
+    }
+  }
   ctx->spec_tables_ok = h->spec_ok != 0;
   {
-    const char *sp = getenv("C1_SPEC");       // 0 exact only, 1 adaptive (default), 2 always speculate
+    const char *sp = getenv("C1_SPEC");       // 0 exact only, 1 material-local (default), 2 always speculate
     ctx->spec_mode = sp ? atoi(sp) : 1;
     if (ctx->spec_mode < 0 || ctx->spec_mode > 2) ctx->spec_mode = 1;
+    const char *sd = getenv("C1_SPEC_DEFER");   // experiments: the predictor's threshold (open decisions per unit)
+    if (sd && atof(sd) > 0) ctx->spec_defer = (float)atof(sd);
   }
   delete h;
   if (me != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "table upload: %s", hipGetErrorString(me)); }
@@ -908,6 +942,7 @@ int c1_ctx_destroy(c1_ctx *ctx) {
   if (ctx->d_tables) hipFree(ctx->d_tables);
   if (ctx->d_opts) hipFree(ctx->d_opts);
   if (ctx->d_spec_totals) hipFree(ctx->d_spec_totals);
+  if (ctx->h_totals) (void)hipHostFree(const_cast<unsigned long long *>(ctx->h_totals));
   (void)hipDeviceSynchronize();
   free_workspace(ctx);
   if (ctx->s_ana) (void)hipStreamDestroy(ctx->s_ana);
@@ -952,8 +987,6 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
   if (mode < 0 || mode > 2) return fail(C1_ERR_ARG, "speculation mode must be 0, 1 or 2, got %d", mode);
   CTX_GUARD(ctx);
   ctx->spec_mode = mode;
-  ctx->spec_last_fraction = 0.0;
-  ctx->spec_exact_calls = 0;
   ctx->q32_last_fraction = 0.0;
   ctx->q32_off_calls = 0;
   ctx->det_last_fraction = 0.0;
@@ -978,11 +1011,23 @@ int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int
   if (units) *units = tot[0];
   if (redone) *redone = tot[1];
   if (reset) {
-    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, 6 * sizeof(unsigned long long), ctx->stream));
-    ctx->spec_seen[0] = ctx->spec_seen[1] = 0;
+    HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, kTotals * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_totals) for (int i = 0; i < kTotals; i++) ctx->h_totals[i] = 0;
     ctx->q32_seen[0] = ctx->q32_seen[1] = 0;
     ctx->det_seen[0] = ctx->det_seen[1] = 0;
   }
+  return C1_OK;
+}
+
+int c1_ctx_speculation_deferred(c1_ctx *ctx, uint64_t *units) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  unsigned long long tot[kTotals];
+  HIP_TRY(hipMemcpyAsync(tot, ctx->d_spec_totals, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (units) *units = tot[6];
   return C1_OK;
 }
 

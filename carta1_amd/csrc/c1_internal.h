@@ -83,6 +83,9 @@ constexpr int kAllocBytes = 32;  // per unit: 52 wl nibbles, amount index, fallb
 constexpr int kCandidateBytes = 8 * 8 + 8 * 32 + 8 * 8;  // per unit: 8 totals + 8 results + 8 lower bounds (bit allocation scratch)
 constexpr int kCandLbOffset = 8 * 8 + 8 * 32;
 constexpr int kEpsFloats = 4;    // per unit (speculative path): error bound of bands 0..2, flags
+constexpr uint32_t kEpsFlagSfOpen = 1u;   // flag word: a scale-factor index is not certain within the bound
+constexpr uint32_t kEpsFlagExact = 2u;    // flag word: the coefficients are the exact kernels' (bounds are zero)
+constexpr int kSpecCheckFrames = 16;      // the speculative analysis re-assesses its material every so many frames of a run
 
 struct C1EncodeLaunch {
   const float *pcm[C1_MAX_CHANNELS];
@@ -108,10 +111,20 @@ struct C1EncodeLaunch {
   uint32_t *redo_count;
   uint32_t *realloc_list;   // the listed units whose scale-factor indices were not certain: their allocation is redone too
   uint32_t *realloc_count;
+  uint32_t *reana_list;     // the listed units whose coefficients are binary32 ones: the exact analysis rebuilds them (units
+  uint32_t *reana_count;    // of runs the exact kernels analysed in the first place are only packed again)
+  // material-local speculation: the speculative analysis estimates, every kSpecCheckFrames frames of a
+  // run, how many decisions of a unit the guards will leave open; past spec_defer it hands the rest of its run to the
+  // exact kernels: defer_list[run * channels + channel] = first unit of the deferred part of that run, 0xffffffff = none
+  uint32_t *defer_list;
+  float spec_defer;         // threshold on the predicted number of open decisions per unit; +inf: never defer
   // list mode: when unit_list is non-null the kernels process units unit_list[0 .. *unit_count) instead of all
   const uint32_t *unit_list;
   const uint32_t *unit_count;
+  int list_runs;         // list mode of the analysis kernels: an entry is the first unit of a run that ends where the run of
+                         // run_frames frames around it ends (the runs the speculative kernel handed over), not a single unit
   int run_frames;        // consecutive frames of one channel a wave walks (set by the launchers, c1k_pick_run)
+  int spread_bits;       // speculative analysis: ceil(log2(workgroups)) for its block -> run permutation, 0 = stream order
 };
 
 struct C1DecodeLaunch {
@@ -164,7 +177,11 @@ void c1k_launch_allocate(const C1EncodeLaunch &L, hipStream_t stream);
 void c1k_launch_alloc_tap(const C1EncodeLaunch &L, double *out, hipStream_t stream);   // test tap: totals and lower bounds of all candidates
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // all_long: every unit has modes [0,0,0]
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
-void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream);
+// running totals (c1_ctx::d_spec_totals) and their page-locked mirror; kind 0 speculative call (counts = list head), 1 binary32
+// quantization of exact coefficients (counts[0] = repacked), 2 speculative detector (counts[0] = rechecked)
+void c1k_launch_spec_totals(unsigned long long *totals, unsigned long long *mirror, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream);
+// the speculative kernel's slot array (L.defer_list) -> dense list of deferred runs; counts[0] = entries, counts[1] = units covered
+void c1k_launch_defer_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *counts, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, bool binary32, hipStream_t stream);   // binary32: opt-in, PCM within rounding noise of the reference
 // kind_mask: bit k = fill the 512-frame segments with (segment & 3) == k (15 = all)
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, int kind_mask, double amp, hipStream_t stream);

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   const int64_t listed_unit = listed ? (int64_t)L.unit_list[item] : 0;
   const int ch = listed ? (int)(listed_unit % L.channels) : (int)(blockIdx.x % L.channels);
   const int64_t f0 = listed ? listed_unit / L.channels : (int64_t)(blockIdx.x / L.channels) * L.run_frames;
-  const int64_t run_frames = listed ? 1 : L.run_frames;
+  // a listed run (material the speculative analysis handed over, c1_k_spec.hip) ends where the run around it ends
+  const int64_t run_frames = listed ? (L.list_runs ? (f0 / L.run_frames + 1) * L.run_frames - f0 : 1) : L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
   lane = lane0;
 
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
       __syncthreads();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+      if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // exact coefficients: bounds of zero
       __syncthreads();
     } else {
       // ---------------- mdctStage with short blocks (encoder.js:170-349), fixed block modes ----------------
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       if (lane >= 60 && lane < 63) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60)] = lane == 60 ? (uint32_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0u;
       __syncthreads();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
+      if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       __syncthreads();
     }
   }

@@ -143,8 +143,8 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
     uint32_t at = 0;
     if (lane == 0) at = atomicAdd(L.redo_count, (uint32_t)n_redo);
     at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-    const uint32_t entry = lane < n_redo ? S.redo[lane] : 0u;
-    if (lane < n_redo) L.redo_list[at + lane] = entry & 0x7fffffffu;
+    const uint32_t entry = lane < n_redo ? S.redo[lane] : 0x40000000u;
+    if (lane < n_redo) L.redo_list[at + lane] = entry & 0x3fffffffu;
     // bit 31: a scale-factor index of the unit was open, so its bits are allocated again as well (the allocation reads
     // nothing but the indices, bitallocation.js:74-142; the exact analysis of the others reproduces the ones it ran on)
     const uint64_t open_mask = __builtin_amdgcn_ballot_w64((entry >> 31) != 0u);
@@ -152,7 +152,16 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
       uint32_t at2 = 0;
       if (lane == 0) at2 = atomicAdd(L.realloc_count, (uint32_t)__popcll(open_mask));
       at2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at2);
-      if ((entry >> 31) != 0u) L.realloc_list[at2 + __popcll(open_mask & ((1ull << lane) - 1ull))] = entry & 0x7fffffffu;
+      if ((entry >> 31) != 0u) L.realloc_list[at2 + __popcll(open_mask & ((1ull << lane) - 1ull))] = entry & 0x3fffffffu;
+    }
+    // bit 30 clear: the coefficients are binary32 ones, the exact analysis has to rebuild them (a unit whose coefficients
+    // are the exact kernels' already -- bounds of zero -- is only packed again)
+    const uint64_t ana_mask = __builtin_amdgcn_ballot_w64((entry & 0x40000000u) == 0u);
+    if (ana_mask != 0) {
+      uint32_t at3 = 0;
+      if (lane == 0) at3 = atomicAdd(L.reana_count, (uint32_t)__popcll(ana_mask));
+      at3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at3);
+      if ((entry & 0x40000000u) == 0u) L.reana_list[at3 + __popcll(ana_mask & ((1ull << lane) - 1ull))] = entry & 0x3fffffffu;
     }
     n_redo = 0;
   };
@@ -312,10 +321,13 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
     if (lane < 53) reinterpret_cast<uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane] = __builtin_bswap32(S.words[lane]);
     if constexpr (SPEC) {
       // flag word of the analysis (a scale-factor index was not certain) or any doubtful mantissa -> exact redo
-      const bool sf_open = __float_as_int(__shfl(h0.eps, 3)) != 0;
+      const uint32_t epsw = __float_as_uint(h0.eps);
+      const bool sf_open = (__builtin_amdgcn_readlane((int)epsw, 3) & (int)kEpsFlagSfOpen) != 0;
       const bool redo = __builtin_amdgcn_ballot_w64(doubtful) != 0 || sf_open;
       if (redo) {
-        if (lane == 0) S.redo[n_redo] = (uint32_t)unit | (sf_open ? 0x80000000u : 0u);
+        // bounds of zero (not even the 2^-70 every speculative bound contains): the exact kernels' coefficients
+        const bool exact = (__builtin_amdgcn_readlane((int)epsw, 0) | __builtin_amdgcn_readlane((int)epsw, 1) | __builtin_amdgcn_readlane((int)epsw, 2)) == 0;
+        if (lane == 0) S.redo[n_redo] = (uint32_t)unit | (sf_open ? 0x80000000u : 0u) | (exact ? 0x40000000u : 0u);
         n_redo++;
       }
     }

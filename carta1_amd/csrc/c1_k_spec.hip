@@ -140,15 +140,76 @@ __device__ __forceinline__ void radix4_round(v2f (&x)[4], v2f wa, v2f wb, v2f wa
   x[3] = pk_fma(t3.yx, PNM, t1);                         // t1 + i t3
 }
 
+// Material-local speculation.  How many decisions of this unit will the guards leave open?  The greedy
+// allocation (bitallocation.js:203-281) levels biasedSF 2^-bits over the BFUs it codes, so with L the log2 of that
+// level -- the root of sum size_b clamp(lb_b - L, 0, 16) = budget, found by Newton steps from the left on a convex
+// piecewise-linear function -- a coefficient of BFU b is quantized with norm ~ 2^(bits_b - 1) / SF_b and its truncation
+// is doubtful with probability ~ 2 eps norm; a scale-factor index is open with probability ~ 2 eps / (0.206 SF_b).
+// The sum P of those probabilities predicts the flagged fraction 1 - exp(-P) (tools/spec_predictor_sim.py: white noise
+// 0.07, pink noise with bursts 0.1-0.3, harmonics over a noise floor 3.6, stationary partials 12-200).  It only steers
+// which kernels compute a unit -- either way the unit ends up bit-identical to the reference's -- so binary32
+// arithmetic and approximate transcendental instructions are good enough.  One lane per BFU.
+__device__ __attribute__((noinline)) bool spec_should_defer(const uint8_t *sfi, int lane, float e0, float e1, float e2,
+                                                  const C1DevEncOpts *O, float threshold) {
+  const int s = lane < 52 ? (int)sfi[lane] : 0;
+  const float size = (float)(lane < 4 ? 8 : lane < 8 ? 4 : lane < 12 ? 8 : lane < 24 ? 6 : lane < 28 ? 7 : lane < 32 ? 9 : lane < 36 ? 10 : lane < 44 ? 12 : 20);
+  const bool act = s > 0;
+  const float sf = (float)s;
+  const float l = __builtin_fmaf(sf, 0.33333334f, -21.0f);            // log2 SCALE_FACTORS[s]
+  const float lb = __builtin_fmaf(O->la_slope, sf, O->la_off);         // log2 of the biased table
+  const float eb = lane >= 36 ? e2 : (lane >= 20 ? e1 : e0);
+  const float sz = act ? size : 0.0f;
+  constexpr float kBudget = 1136.0f;                                   // bits the 52-BFU candidate spends (1696 - 40 - 10 * 52)
+  const float n_all = wave_sum(sz);
+  if (!(n_all > 0.0f)) return false;                                   // nothing coded: nothing to doubt
+  float Lw = (wave_sum(sz * lb) - kBudget) * __builtin_amdgcn_rcpf(n_all);
+#pragma unroll 1
+  for (int it = 0; it < 3; it++) {
+    const float d = lb - Lw;
+    const float bits = fminf(fmaxf(d, 0.0f), 16.0f);
+    const float spend = wave_sum(sz * bits);
+    const float n = wave_sum((d > 0.0f && d < 16.0f) ? sz : 0.0f);
+    if (n > 0.0f) Lw += (spend - kBudget) * __builtin_amdgcn_rcpf(n);
+  }
+  const float bits = fminf(fmaxf(lb - Lw, 0.0f), 16.0f);
+  const float inv_sf = __builtin_amdgcn_exp2f(-l);
+  const float pm = (act && bits >= 1.0f) ? size * eb * inv_sf * __builtin_amdgcn_exp2f(bits) : 0.0f;
+  const float ps = act ? fminf(1.0f, 9.7f * eb * inv_sf) : 0.0f;
+  const float P = wave_sum(pm + ps);
+  return !(P <= threshold);                                            // bounds that are not finite: exact kernels
+}
+
 // SHORT = false: fixed block modes [0,0,0].  SHORT = true: all three bands coded with short blocks (any non-zero fixed
 // modes, e.g. [2,2,3]): sixteen 64-sample MDCTs = 16-point transforms per frame, rounds A and B only.
+// Which (run, channel) a workgroup takes: a pseudo-random bijection of the block index.  Workgroups are handed to the
+// compute units round robin, and material comes in stretches (BASELINE configs[3]: 512-frame segments = 16 consecutive
+// (run, channel) pairs, four kinds with period 64): in index order every compute unit kept getting the same kind, and
+// the ones that only saw the tonal segments -- whose runs leave after their first frame -- idled while the others
+// carried the whole launch (measured: 3.1 ms instead of 2.6 for a quarter of tonal runs).  Bijection on [0, 2^bits):
+// odd multiplications and xor-shifts; values >= n walk on along their cycle (bits = ceil(log2 n): fewer than two
+// steps on average).  Wave-uniform, scalar unit.
+__device__ __forceinline__ uint32_t spread_block(uint32_t b, uint32_t n, int bits) {
+  if (bits < 4) return b;
+  const uint32_t mask = (1u << bits) - 1u;
+  const int sh = (bits >> 1) + 1;
+  uint32_t x = b;
+  do {
+    x = (x * 0x9E3779B1u) & mask;
+    x ^= x >> sh;
+    x = (x * 0x85EBCA6Bu) & mask;
+    x ^= x >> sh;
+  } while (x >= n);
+  return x;
+}
+
 template <bool SHORT>
 __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) {
   __shared__ SpecLds S;
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  const int ch = blockIdx.x % L.channels;
-  const int64_t f0 = (int64_t)(blockIdx.x / L.channels) * L.run_frames;
+  const uint32_t slot = L.spread_bits > 0 ? spread_block(blockIdx.x, gridDim.x, L.spread_bits) : blockIdx.x;
+  const int ch = (int)(slot % (uint32_t)L.channels);
+  const int64_t f0 = (int64_t)(slot / (uint32_t)L.channels) * L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
   float *mem = S.mem;
 
@@ -180,6 +241,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
   }
+  uint32_t deferred_from = 0xffffffffu;       // first unit of the part of this run that goes to the exact kernels (none)
   for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = (f >= f0);
     TablesPtr T = tables_for_this_frame(L.tables);
@@ -534,21 +596,83 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     }
     const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;
     __syncthreads();
+    // every kSpecCheckFrames frames: is this material worth speculating on?  If not, the rest of the run (this frame
+    // included: nothing of it has been handed on yet but the coefficients, which the exact kernel overwrites) goes to
+    // the exact kernels' run list
+    if (L.defer_list != nullptr && (((int)(f - f0)) & (kSpecCheckFrames - 1)) == 0) {
+      if (spec_should_defer(S.sfi, lane, e0, e1, e2, L.opts, L.spec_defer)) { deferred_from = (uint32_t)unit; break; }
+    }
     if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
     if (lane == 0) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(e0, e1, e2, __int_as_float(any_unstable ? 1 : 0));
     __syncthreads();
   }
+  // one slot per run and channel, written by every workgroup (no list appends: tens of thousands of atomics on one counter
+  // serialise at ~6-20 ns each, which cost 0.5 ms per 2 M units when a quarter of the runs were handed over)
+  if (L.defer_list != nullptr && lane0 == 0) L.defer_list[slot] = deferred_from;
 }
 
-__global__ void k_spec_totals(unsigned long long *totals, unsigned long long units, const uint32_t *redo_count) {
-  totals[0] += units;
-  totals[1] += *redo_count;
+// the slots of the deferred runs -> a dense list for the exact kernels (one atomic per wave; the order of the list is
+// free: every entry is processed on its own).  counts[0] = entries, counts[1] = units they cover.
+__global__ __launch_bounds__(256) void k_defer_compact(const uint32_t *__restrict__ slots, uint32_t n_slots, uint32_t *__restrict__ list, uint32_t *__restrict__ counts,
+                                                        int channels, int run_frames, uint32_t frames) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t u = i < n_slots ? slots[i] : 0xffffffffu;
+  const bool on = u != 0xffffffffu;
+  uint32_t covered = 0;
+  if (on) {
+    const uint32_t f = u / (uint32_t)channels;
+    uint32_t end = (f / (uint32_t)run_frames + 1u) * (uint32_t)run_frames;
+    if (end > frames) end = frames;
+    covered = end - f;
+  }
+  const uint64_t mask = __builtin_amdgcn_ballot_w64(on);
+  if (mask == 0) return;
+  int cov = (int)covered;
+  cov = wave_inclusive_scan(cov);
+  const int lane = threadIdx.x & 63;
+  uint32_t at = 0;
+  if (lane == 63) {
+    at = atomicAdd(counts, (uint32_t)__popcll(mask));
+    atomicAdd(counts + 1, (uint32_t)cov);
+  }
+  at = (uint32_t)__builtin_amdgcn_readlane((int)at, 63);
+  if (on) list[at + __popcll(mask & ((1ull << lane) - 1ull))] = u;
+}
+
+// kind 0: a speculative call -- counts = the list head (redo, realloc, re-analysis, deferred runs, deferred units);
+// kind 1: exact coefficients quantized in binary32 -- counts[0] = units packed again;  kind 2: the speculative detector --
+// counts[0] = units rechecked.  mirror: page-locked host memory the encode entry reads without synchronising.
+__global__ void k_spec_totals(unsigned long long *totals, unsigned long long *mirror, unsigned long long units, const uint32_t *counts, int kind) {
+  if (kind == 0) {
+    const unsigned long long deferred = counts[4];
+    totals[0] += units - deferred;
+    totals[1] += counts[2];
+    totals[2] += deferred;
+    totals[3] += counts[0] - counts[2];
+    totals[6] += deferred;
+  } else if (kind == 1) {
+    totals[2] += units;
+    totals[3] += counts[0];
+  } else {
+    totals[4] += units;
+    totals[5] += counts[0];
+  }
+  if (mirror) {
+    for (int i = 0; i < 7; i++) mirror[i] = totals[i];
+    __threadfence_system();
+  }
 }
 
 }  // namespace
 
-void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *redo_count, hipStream_t stream) {
-  hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, (unsigned long long)units, redo_count);
+void c1k_launch_spec_totals(unsigned long long *totals, unsigned long long *mirror, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream) {
+  hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, mirror, (unsigned long long)units, counts, kind);
+}
+void c1k_launch_defer_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *counts, hipStream_t stream) {
+  const int run = c1k_pick_run(L.frames, L.channels, 0);
+  const int64_t slots = (L.frames + run - 1) / run * L.channels;
+  hipLaunchKernelGGL(k_defer_compact, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, (const uint32_t *)L.defer_list, (uint32_t)slots, list, counts,
+                     L.channels, run, (uint32_t)L.frames);
 }
 
 void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, bool all_short, hipStream_t stream) {
@@ -557,6 +681,9 @@ void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, bool all_short, hipStrea
   L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
   const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
   const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
+  static const bool no_spread = getenv("C1_NO_SPREAD") != nullptr;     // experiments: workgroups in stream order
+  L.spread_bits = 0;
+  if (!no_spread) while ((1ll << L.spread_bits) < (int64_t)grid.x) L.spread_bits++;
   if (all_short) hipLaunchKernelGGL((k_analysis_spec<true>), grid, block, 0, stream, L);
   else hipLaunchKernelGGL((k_analysis_spec<false>), grid, block, 0, stream, L);
 }

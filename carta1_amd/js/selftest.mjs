@@ -64,7 +64,7 @@ async function main() {
   rejected = null
   try { await c1.decodeAeaPcm('nope') } catch (err) { rejected = err }
   ok(rejected instanceof TypeError && rejected.message === 'ATRAC1 decoding requires AEA bytes or a Blob', 'decodeAeaPcm TypeError')
-  ok(native().abiVersion() === 2, 'addon loads')
+  ok(native().abiVersion() === 3, 'addon loads')
 
   if (!gpu) {
     let err = null

@@ -39,7 +39,7 @@ extern "C" {
 #define C1_FRAME_SAMPLES 512
 #define C1_UNIT_BYTES 212
 #define C1_MAX_CHANNELS 2
-#define C1_ABI_VERSION 2
+#define C1_ABI_VERSION 3
 
 enum {
   C1_OK = 0,
@@ -113,14 +113,19 @@ int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches);
  * [0,0,0] the library first computes the coefficients in binary32 together with a proven bound on their distance
  * from the reference's binary64-then-rounded values, accepts every sound unit whose decisions are the same for all
  * values within the bound, and re-encodes the others with the exact kernels: the result is bit-identical to the
- * exact path by construction.  mode: 0 = exact kernels only, 1 = adaptive (default; a stream that had to redo more
- * than 30 % of its units is sent to the exact kernels, re-probed every 16th call), 2 = always speculate.
+ * exact path by construction.  mode: 0 = exact kernels only; 1 = material-local (default): every 16 frames of a
+ * 64-frame run the speculative kernel predicts, from the scale-factor indices and its bound, how many decisions of a
+ * unit the guards will leave open, and past a threshold hands the rest of that run to the exact kernels -- the choice
+ * is taken per run inside the call, never carried from one call or stream to the next; 2 = always speculate.
  * The environment variable C1_SPEC (0/1/2) sets the default of new contexts. */
 int c1_ctx_set_speculation(c1_ctx *ctx, int mode);
-/* units encoded through the speculative pass and units among them that were redone exactly, since the context was
- * created (or since the last call with reset != 0); synchronises the context's stream */
+/* units that stayed with the speculative analysis and units among them that were redone exactly, since the context
+ * was created (or since the last call with reset != 0); synchronises the context's stream */
 int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int reset);
-/* The exact paths (transient detection, mixed fixed modes, streams the adaptive mode keeps off the speculative analysis)
+/* units of speculative calls whose runs the speculative analysis handed to the exact kernels (mode 1; cleared by
+ * c1_ctx_speculation_stats(reset)); synchronises the context's stream */
+int c1_ctx_speculation_deferred(c1_ctx *ctx, uint64_t *units);
+/* The exact paths (transient detection, mixed fixed modes, runs the speculative analysis handed over)
  * quantize the reference's coefficients in binary32 with the same guard band and pack the few units it cannot certify
  * again in binary64: units packed that way so far and units packed twice (cleared by c1_ctx_speculation_stats(reset)). */
 int c1_ctx_quantization_stats(c1_ctx *ctx, uint64_t *units, uint64_t *repacked);
@@ -141,7 +146,9 @@ int c1_ctx_set_decode_precision(c1_ctx *ctx, int binary32);
  *      (qmfAnalysisStage :57-96, blockSelectorStage :111-152, mdctStage :170-349,
  *      quantizationStage :365-418) plus serializeFrame (serialization.js:41-98), batched ----- */
 
-/* device-resident: pcm[c] and units are DEVICE pointers; asynchronous on the context's stream */
+/* device-resident: pcm[c] and units are DEVICE pointers; asynchronous on the context's stream: the call only enqueues
+ * work and never waits for the device (it blocks only to grow the workspace on a first, larger call, or when the
+ * options change while earlier calls are still queued) */
 int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
                      int halo_frames, const c1_encode_options *opts, uint8_t *units);
 /* host-resident: copies in, runs c1_encode_device, copies out, synchronises.

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in declared:
         assert hasattr(lib, name), 'library does not export ' + name
     assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
-    assert lib.c1_abi_version() == 2
+    assert lib.c1_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

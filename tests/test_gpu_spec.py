@@ -103,43 +103,92 @@ def test_white_noise_redo_fraction_and_identity(ctx, bias, modes):
     assert np.array_equal(spec[:1024], want)
 
 
-def test_adaptive_mode_sends_tonal_streams_to_the_exact_kernels(ctx):
-    import carta1_amd as c1
-    t = np.arange(256 * 512)
-    tone = (0.5 * np.sin(2 * np.pi * 1000 * t / 44100)).astype(np.float32)
-    opts = c1.EncoderOptions(LONG)
-    ctx.set_speculation(1)
-    ctx.speculation_stats(reset=True)
-    a = ctx.encode([tone], opts).copy()          # probes: nearly every unit fails the guard band
-    u1, r1 = ctx.speculation_stats()
-    b = ctx.encode([tone], opts).copy()          # sent to the exact kernels: the totals do not move
-    u2, r2 = ctx.speculation_stats()
-    assert u1 == 256 and r1 > 0.5 * u1 and (u2, r2) == (u1, r1)
-    assert np.array_equal(a, b)
-    ctx.set_speculation(1)
-
-
-def test_adaptive_mode_probes_a_slice_every_16th_call(ctx):
-    """a stream in exact mode speculates only the first 32 768 frames of every 16th call; the units never change"""
-    import carta1_amd as c1
-    frames = 40000
+def tone(frames, f=1000.0, amp=0.5, f2=None):
     t = np.arange(frames * 512)
-    tone = (0.4 * np.sin(2 * np.pi * 440 * t / 44100) + 0.1 * np.sin(2 * np.pi * 3520 * t / 44100)).astype(np.float32)
+    x = amp * np.sin(2 * np.pi * f * t / 44100)
+    if f2:
+        x = x + 0.2 * amp * np.sin(2 * np.pi * f2 * t / 44100)
+    return x.astype(np.float32)
+
+
+def test_material_local_mode_hands_tonal_runs_to_the_exact_kernels(ctx):
+    """default mode: the speculative kernel's predictor rejects tonal material run by run"""
+    import carta1_amd as c1
+    x = tone(256)
     opts = c1.EncoderOptions(LONG)
     ctx.set_speculation(0)
-    exact = ctx.encode([tone], opts).copy()
+    exact = ctx.encode([x], opts).copy()
     ctx.set_speculation(1)
     ctx.speculation_stats(reset=True)
-    assert np.array_equal(ctx.encode([tone], opts), exact)       # first call of the stream: speculated as a whole
-    u1, r1 = ctx.speculation_stats()
-    assert u1 == frames and r1 > 0.5 * u1
-    for _ in range(15):
-        assert np.array_equal(ctx.encode([tone], opts), exact)   # exact kernels: the totals stand still
-    assert ctx.speculation_stats() == (u1, r1)
-    assert np.array_equal(ctx.encode([tone], opts), exact)       # the 17th call probes a slice
-    u2, r2 = ctx.speculation_stats()
-    assert u2 == u1 + 32768 and r2 > r1
+    a = ctx.encode([x], opts).copy()
+    u, r = ctx.speculation_stats()
+    d = ctx.speculation_deferred()
+    assert d >= 256 - 16 and u + d == 256, (u, r, d)                      # every run left at its first check (the onset
+                                                                          # from silence may pass the first one)
+    assert np.array_equal(a, exact)
+    want, _ = O.encode_stream([x], fixed_modes=(0, 0, 0))
+    assert np.array_equal(a, want)
+    # forced speculation on the same stream: nearly every unit fails the guard band and is redone
+    ctx.set_speculation(2)
+    ctx.speculation_stats(reset=True)
+    b = ctx.encode([x], opts).copy()
+    u, r = ctx.speculation_stats()
+    assert u == 256 and r > 0.5 * u and ctx.speculation_deferred() == 0
+    assert np.array_equal(b, exact)
     ctx.set_speculation(1)
+
+
+@pytest.mark.parametrize('modes', [(0, 0, 0), (2, 2, 3)], ids=['long', 'short'])
+def test_material_local_mode_decides_per_run_and_carries_nothing_over(ctx, modes):
+    """two channels alternate noise and tones in opposite phase, 128 frames each: the tonal runs -- and only they -- go
+    to the exact kernels, whatever the other channel or the previous call held"""
+    import carta1_amd as c1
+    seg = 128
+    w1, w2 = O.gen_white(11, seg * 512), O.gen_pinkT(12, seg * 512)
+    t1, t2 = tone(seg, 440.0, 0.4, 3520.0), tone(seg, 1234.5, 0.7)
+    ch0 = np.concatenate([w1, t1, w2, t2])
+    ch1 = np.concatenate([t2, w2, t1, w1])
+    opts = c1.EncoderOptions({'fixedBlockModes': list(modes)})
+    ctx.set_speculation(1)
+    ctx.speculation_stats(reset=True)
+    got = ctx.encode([ch0, ch1], opts).copy()
+    u, r = ctx.speculation_stats()
+    d = ctx.speculation_deferred()
+    want, _ = O.encode_stream([ch0, ch1], fixed_modes=modes)
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:8]
+    # segment boundaries are run boundaries here.  The four tonal segments are deferred -- a tone's onset frame is
+    # broadband, so a segment may be left at its second check (16 frames late), and the first run of a noise segment
+    # right behind a tone may still be handed over (its first unit holds the tone's windowed tail)
+    assert u + d == 8 * seg and 4 * seg - 4 * 16 <= d <= 4 * seg + 4 * 64, (d, u, r)
+    assert r < 0.35 * u, (u, r)                                  # of the units that WERE speculated few are redone
+    uq, rq = ctx.quantization_stats()
+    assert uq >= d                                               # the deferred runs are quantized in binary32 behind a bound of zero
+    # nothing is carried from call to call: noise right after tones defers nothing, tones after noise (nearly) everything
+    ctx.speculation_stats(reset=True)
+    ctx.encode([t1], opts)
+    d1 = ctx.speculation_deferred()
+    assert seg - 16 <= d1 <= seg
+    ctx.encode([w1], opts)
+    assert ctx.speculation_deferred() == d1
+    ctx.encode([t2], opts)
+    assert seg - 16 <= ctx.speculation_deferred() - d1 <= seg
+
+
+def test_material_change_inside_a_run(ctx):
+    """material that turns tonal (or stops being tonal) in the middle of a 64-frame run: the run is handed over at the next
+    16-frame check and stays with the exact kernels until it ends; bytes never change"""
+    import carta1_amd as c1
+    x = np.concatenate([O.gen_white(21, 100 * 512), tone(100, 2000.0, 0.6), O.gen_white(22, 100 * 512)])
+    opts = c1.EncoderOptions(LONG)
+    ctx.set_speculation(1)
+    ctx.speculation_stats(reset=True)
+    got = ctx.encode([x], opts).copy()
+    d = ctx.speculation_deferred()
+    want, _ = O.encode_stream([x], fixed_modes=(0, 0, 0))
+    assert np.array_equal(got, want)
+    # tones occupy frames 100..199: noticed at the check of frame 112 at the latest (the run 64..127 is left there),
+    # runs 128..191 at their first frame, run 192..255 at 192 and kept to its end although the tone stops at 200
+    assert 100 + 28 <= d <= 100 + 12 + 56 + 16, d
 
 
 def test_halo_and_unaligned_runs(ctx):
