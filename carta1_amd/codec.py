@@ -275,6 +275,12 @@ class Context:
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
             C.c_void_p(coefs_ptr), C.c_void_p(eps_ptr), C.c_void_p(side_ptr)))
 
+    def pack_spec_tap_device(self, coefs_ptr, eps_ptr, side_ptr, alloc_ptr, units, units_out_ptr, lists_ptr, all_long=True):
+        """Test tap: the speculative quantizer + packer on caller-supplied coefficients, bounds and records (device pointers)."""
+        capi.check(capi.load().c1_pack_spec_tap_device(
+            self._h, C.c_void_p(coefs_ptr), C.c_void_p(eps_ptr), C.c_void_p(side_ptr), C.c_void_p(alloc_ptr), units,
+            1 if all_long else 0, C.c_void_p(units_out_ptr), C.c_void_p(lists_ptr)))
+
 
 def encode_multi(channels, options=None, devices=(0,)):
     """c1_encode_batch_multi: the batch sharded over `devices` (contiguous frame ranges, one host thread and context

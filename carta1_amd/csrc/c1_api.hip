@@ -1254,6 +1254,31 @@ int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, in
   return C1_OK;
 }
 
+int c1_pack_spec_tap_device(c1_ctx *ctx, const float *coefs, const float *eps, const uint8_t *side, const uint8_t *alloc,
+                            int64_t units, int all_long, uint8_t *units_out, uint32_t *lists) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (units < 0 || units > kMaxChunkFrames) return fail(C1_ERR_ARG, "bad unit count");
+  if (!coefs || !eps || !side || !alloc || !units_out || !lists) return fail(C1_ERR_ARG, "NULL argument");
+  if (((uintptr_t)coefs | (uintptr_t)eps) & 15) return fail(C1_ERR_ARG, "coefs and eps must be 16-byte aligned device pointers");
+  if (!ctx->spec_tables_ok) return fail(C1_ERR_STATE, "the installed tables fail the checks the error bound relies on");
+  HIP_TRY(hipMemsetAsync(lists, 0, kListHead * sizeof(uint32_t), ctx->stream));
+  if (units == 0) return C1_OK;
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  L.channels = 1; L.frames = units;
+  L.tables = ctx->d_tables; L.opts = ctx->d_opts;
+  L.coefs = const_cast<float *>(coefs); L.eps = const_cast<float *>(eps);
+  L.side = const_cast<uint8_t *>(side); L.alloc = const_cast<uint8_t *>(alloc);
+  L.units = units_out;
+  L.redo_count = lists; L.realloc_count = lists + 1; L.reana_count = lists + 2;
+  L.redo_list = lists + kListHead; L.realloc_list = lists + kListHead + units; L.reana_list = lists + kListHead + 2 * units;
+  c1k_launch_pack_spec(L, all_long != 0, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
 // ---- streamed host path --------------------------------------------------------------------------------------
 namespace {
 constexpr int64_t kStreamChunkFrames = 32768;   // frames per channel per chunk of the streamed host path

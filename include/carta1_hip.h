@@ -284,6 +284,17 @@ int c1_alloc_bounds_device(c1_ctx *ctx, const uint8_t *side, int64_t units, cons
 int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                           const c1_encode_options *opts, float *coefs, float *eps, uint8_t *side);
 
+/* Test tap of the speculative quantizer on its own (k_pack<.., SPEC>: quantization.js:34-56 in binary32 behind the guard
+ * band of DESIGN.md 3b, serializeFrame serialization.js:41-98).  The caller supplies what the analysis and allocation
+ * kernels would: coefs units*512 floats (coefficient order of quantizationStage), eps units*4 floats (bounds of bands
+ * 0..2; flag word: bit 0 = a scale-factor index is open), side units*64 bytes (sfi[52], modes byte), alloc units*32 bytes
+ * (52 word-length nibbles, low nibble first; last dword: fallback flag bit 27, BFU-amount index bits 28..30).  Out:
+ * units_out units*212 bytes, and lists = 8 + 3*units uint32: [0] [1] [2] the lengths of the redo, reallocation and
+ * re-analysis lists, which start at 8, 8 + units and 8 + 2*units.  Device pointers.  tests/test_gpu_pack_guard.py
+ * checks kernel == CPU model (tests/model/pack_model.c) on coefficients built to sit on the guard band's edge. */
+int c1_pack_spec_tap_device(c1_ctx *ctx, const float *coefs, const float *eps, const uint8_t *side, const uint8_t *alloc,
+                            int64_t units, int all_long, uint8_t *units_out, uint32_t *lists);
+
 #ifdef __cplusplus
 }
 #endif

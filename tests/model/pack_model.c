@@ -31,8 +31,9 @@ static int sf_index(float maxabs, uint32_t m1, uint32_t m2) {
 
 /* The scale-factor guard: coefficients in BFU-major slot order (BFU b = slots first[b] .. first[b] + SPECS[b]),
  * eps[3] the per-band bounds.  Writes the accepted index (that of the low end, as the kernel stores it) and returns 1
- * when any BFU's index is not certain within the bound. */
-int pack_model_sf(const float *slots, const float eps[3], uint32_t m1, uint32_t m2, int sfi_out[52]) {
+ * when any BFU's index is not certain within the bound.
+ * open_out (optional): per BFU, 1 when that BFU's index is open. */
+int pack_model_sf(const float *slots, const float eps[3], uint32_t m1, uint32_t m2, int sfi_out[52], int *open_out) {
   int unstable = 0, first = 0;
   for (int b = 0; b < 52; b++) {
     float mx = 0.0f;
@@ -42,7 +43,9 @@ int pack_model_sf(const float *slots, const float eps[3], uint32_t m1, uint32_t 
     const float lo = fmaxf((mx - e) * 0.99999976f, 0.0f), hi = (mx + e) * 1.00000024f;
     const int s_lo = sf_index(lo, m1, m2), s_hi = sf_index(hi, m1, m2);
     sfi_out[b] = s_lo;
-    if (!(s_lo == s_hi && e < INFINITY)) unstable = 1;
+    const int open = !(s_lo == s_hi && e < INFINITY);
+    if (open_out) open_out[b] = open;
+    if (open) unstable = 1;
   }
   return unstable;
 }
@@ -58,9 +61,10 @@ static int32_t cvt_i32(float x) {
 /* The quantizer of k_pack<.., SPEC>.  slots: coefficients in BFU-major slot order; sfi/wl: the unit's allocation
  * (wl index 0..15, BFUs >= nbfu coded with 0 bits); norm32[64 * 16] = fl32(quantRange(wl) / SCALE_FACTORS[sfi]).
  * q_out: mantissas in slot order.  Returns 1 when any mantissa is doubtful (the unit goes to the redo list).
- * worst_out (optional): the largest |fract(a) - 1/2| + et seen. */
+ * worst_out (optional): the largest |fract(a) - 1/2| + et seen.  doubt_out (optional): per slot, 1 when that mantissa is
+ * doubtful by itself (the kernel only keeps the unit's maximum). */
 int pack_model_quantize(const float *slots, const float eps[3], const int sfi[52], const int wl[52], int nbfu,
-                        const float *norm32, int q_out[512], float *worst_out) {
+                        const float *norm32, int q_out[512], float *worst_out, int *doubt_out) {
   uint32_t worst = 0u;
   int first = 0;
   for (int b = 0; b < 52; b++) {
@@ -80,6 +84,7 @@ int pack_model_quantize(const float *slots, const float eps[3], const int sfi[52
       const float t = fabsf(d - 0.5f) + et;
       const uint32_t tu = f2u(t);
       if (tu > worst) worst = tu;
+      if (doubt_out) doubt_out[first + j] = !(tu < 0x3EFFFFFCu);
       int32_t q = cvt_i32(copysignf(a, x));
       q = q < -range ? -range : (q > range ? range : q);
       q_out[first + j] = q;

@@ -33,8 +33,8 @@ def lib():
                                    '-o', SO, SRC, '-lm'])
         L = C.CDLL(SO)
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
-        L.pack_model_sf.argtypes = [fp, fp, C.c_uint32, C.c_uint32, ip]
-        L.pack_model_quantize.argtypes = [fp, fp, ip, ip, C.c_int, fp, ip, fp]
+        L.pack_model_sf.argtypes = [fp, fp, C.c_uint32, C.c_uint32, ip, ip]
+        L.pack_model_quantize.argtypes = [fp, fp, ip, ip, C.c_int, fp, ip, fp, ip]
         _lib = L
     return _lib
 
@@ -76,22 +76,25 @@ def to_slots(coefs, modes=(0, 0, 0)):
     return out
 
 
-def sf_guard(slots, eps):
-    """-> (sfi[52] as the kernel stores them, unstable flag)"""
+def sf_guard(slots, eps, per_bfu=False):
+    """-> (sfi[52] as the kernel stores them, unstable flag of the unit[, which BFUs are open])"""
     m1, m2 = sf_fraction_patterns()
     slots = np.ascontiguousarray(slots, dtype=np.float32)
     eps = np.ascontiguousarray(eps, dtype=np.float32)
     sfi = np.zeros(52, dtype=np.int32)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
-    un = lib().pack_model_sf(slots.ctypes.data_as(fp), eps.ctypes.data_as(fp), m1, m2, sfi.ctypes.data_as(ip))
+    opened = np.zeros(52, dtype=np.int32)
+    un = lib().pack_model_sf(slots.ctypes.data_as(fp), eps.ctypes.data_as(fp), m1, m2, sfi.ctypes.data_as(ip), opened.ctypes.data_as(ip))
+    if per_bfu:
+        return sfi, bool(un), opened.astype(bool)
     return sfi, bool(un)
 
 
 _norm32 = None
 
 
-def quantize(slots, eps, sfi, wl, nbfu):
-    """-> (mantissas[512] in slot order, doubtful flag, worst |fract - 1/2| + et)"""
+def quantize(slots, eps, sfi, wl, nbfu, per_slot=False):
+    """-> (mantissas[512] in slot order, doubtful flag, worst |fract - 1/2| + et[, which mantissas are doubtful])"""
     global _norm32
     if _norm32 is None:
         _norm32 = norm32_table()
@@ -102,8 +105,11 @@ def quantize(slots, eps, sfi, wl, nbfu):
     q = np.zeros(512, dtype=np.int32)
     worst = np.zeros(1, dtype=np.float32)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    doubt = np.zeros(512, dtype=np.int32)
     d = lib().pack_model_quantize(slots.ctypes.data_as(fp), eps.ctypes.data_as(fp), sfi.ctypes.data_as(ip), wl.ctypes.data_as(ip),
-                                  int(nbfu), _norm32.ctypes.data_as(fp), q.ctypes.data_as(ip), worst.ctypes.data_as(fp))
+                                  int(nbfu), _norm32.ctypes.data_as(fp), q.ctypes.data_as(ip), worst.ctypes.data_as(fp), doubt.ctypes.data_as(ip))
+    if per_slot:
+        return q, bool(d), float(worst[0]), doubt.astype(bool)
     return q, bool(d), float(worst[0])
 
 
