@@ -21,7 +21,7 @@ ALGORITHMIC bytes of the path (2048 B PCM read + 212 B unit written per mono fra
 the other single-GPU BASELINE configs: config 3 at its full size (10 M frames, detection on, encode + decode, parity of
 a 4096-frame subset against the oracle), config 5 (3 biases x 2 mode sets, 1 M frames each), decode, the tonal case
 and the exact-kernels-only rate of the headline.  `config4_share` is the per-GPU share of config 4 (12.5 M frames of
-the mixed corpus), run on every rank when N > 1 or with --config4.
+the mixed corpus): part of the default N = 1 line, and run on every rank when N > 1.
 """
 import argparse
 import hashlib
@@ -118,6 +118,43 @@ def cpu_baseline(modes, bias, frames_one, frames_each):
                               '(SURVEY.md 6); it cannot travel to the GPU box'}
 
 
+def load_pmc():
+    """profiles/pmc_traffic.json, only when it was collected from the kernel sources that are running"""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        pmc = json.load(open(path))
+    except Exception:   # noqa: BLE001
+        return None, 'profiles/pmc_traffic.json missing'
+    if pmc.get('source_sha') != source_sha():
+        return None, 'profiles/pmc_traffic.json is from other kernel sources (%s): not used' % pmc.get('source_sha')
+    return pmc, 'profiles/pmc_traffic.json@' + pmc['source_sha']
+
+
+def valu_roofline(kind, launch_ms, units_per_launch, section):
+    """The compute ceiling next to the HBM one (SURVEY.md 8d "report both").  Every wave64 vector instruction occupies its
+    SIMD for 4 cycles (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles on every kernel), so a launch that issues I
+    vector instructions needs 4 I SIMD-cycles of the 4 x SQ_BUSY_CU_CYCLES its compute units were busy for; `frac` is that
+    ratio from the counter passes under profiles/ (same sources only), `achieved` the same instruction count against the
+    launch time measured in THIS run, `peak` = 1024 SIMDs x the clock the counters imply."""
+    pmc, source = load_pmc()
+    if pmc is None or section is None or section not in pmc.get('sections', {}) or kind not in pmc['sections'][section]:
+        return {'bound': 'valu', 'frac': None, 'source': source}
+    e = pmc['sections'][section][kind]
+    scale = units_per_launch / pmc['sections'][section]['units_per_launch']
+    insts = e['valu_insts_per_launch'] * scale
+    clock_ghz = e['busy_cu_cycles_per_launch'] / 256.0 / (e['profiled_launch_ms'] * 1e-3) / 1e9 if e.get('profiled_launch_ms') else None
+    out = {'bound': 'valu', 'kernel': e['kernel'], 'unit': 'G SIMD-cycles/s',
+           'vector_instructions_per_sound_unit': e['valu_insts_per_launch'] / pmc['sections'][section]['units_per_launch'],
+           'frac': e['valu_issue_cycles_per_launch'] / (4.0 * e['busy_cu_cycles_per_launch']),
+           'lds_busy_frac': (e['lds_active_cycles_per_launch'] / e['busy_cu_cycles_per_launch']) if e.get('lds_active_cycles_per_launch') else None,
+           'achieved': 4.0 * insts / (launch_ms * 1e-3) / 1e9, 'source': source}
+    if clock_ghz:
+        out['peak'] = 1024 * clock_ghz
+        out['clock_ghz_from_counters'] = clock_ghz
+        out['frac_this_run'] = out['achieved'] / out['peak']
+    return out
+
+
 def self_launch(args):
     """--gpus N outside torch.distributed: start the N ranks as fresh processes before any GPU call."""
     s = socket.socket()
@@ -144,6 +181,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=32768, help='stereo frames for the one-thread CPU baseline (0 = skip)')
     ap.add_argument('--no-extras', action='store_true', help='headline workload only (profiling runs)')
     ap.add_argument('--config4', action='store_true', help='also run the per-GPU share of config 4 (12.5 M mixed frames)')
+    ap.add_argument('--no-config4', action='store_true', help='skip the config-4 share in the default N = 1 run')
     ap.add_argument('--config4-frames', type=int, default=12500000)
     ap.add_argument('--config3-frames', type=int, default=10 << 20)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL); gloo for rehearsals')
@@ -189,11 +227,13 @@ def main():
         return float(t.item())
 
     def options_for(modes, bias):
+        # pow(SCALE_FACTORS, bias) comes from the package's own copy of the V8-produced tables (carta1_amd/biased_tables.json)
         opt = {'allocationBias': bias}
         if modes is not None:
             opt['fixedBlockModes'] = modes
-        import oracle_lib as O
-        return c1.EncoderOptions(opt, biased_table=O.biased_table(bias))
+        if c1.codec.packaged_biased_table(bias) is None:
+            sys.exit('allocationBias %s: no V8-produced table in the package (parity would be unpinned)' % bias)
+        return c1.EncoderOptions(opt)
 
     def generate(frames, signal, seeds, skip_frames=0):
         pcm = [torch.empty(frames * 512, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -238,8 +278,11 @@ def main():
         ctx.speculation_stats(reset=True)
         elapsed, km = timed(lambda: ctx.encode_device(ptrs, frames, units.data_ptr(), c_options=c_opts), steps, warmup, KINDS)
         su, sr = ctx.speculation_stats()
+        deferred = ctx.speculation_deferred()
         ctx.set_speculation(1)
-        return units, elapsed, km, (sr / su if su else None), su
+        # su: units that stayed with the speculative analysis, sr: units among them redone exactly, deferred: units of runs the
+        # speculative kernel's predictor handed to the exact kernels (material-local speculation)
+        return units, elapsed, km, (sr / su if su else None), su + deferred, {'speculated_units': su, 'redone_units': sr, 'deferred_to_exact_units': deferred}
 
     def parity_subset(pcm, units, frames_sub, modes, bias, threshold=1.0):
         """units of the first frames_sub frames against the oracle run on the very PCM the device holds"""
@@ -264,9 +307,9 @@ def main():
         out_pcm = [torch.empty(frames * 512, dtype=torch.float32, device=dev) for _ in range(2)]
         out_ptrs = [p.data_ptr() for p in out_pcm]
         elapsed, kernel_ms = timed(lambda: ctx.decode_device(units.data_ptr(), 2, frames, out_ptrs), args.steps, args.warmup, ('decode',))
-        redo_fraction, spec_units = None, 0
+        redo_fraction, spec_units, spec_detail = None, 0, None
     else:
-        units, elapsed, kernel_ms, redo_fraction, spec_units = encode_run(pcm, frames, c_opts, args.steps, args.warmup)
+        units, elapsed, kernel_ms, redo_fraction, spec_units, spec_detail = encode_run(pcm, frames, c_opts, args.steps, args.warmup)
 
     line = None
     if rank == 0:
@@ -284,17 +327,11 @@ def main():
         achieved = BYTES_PER_STEREO_FRAME * frames_per_launch / avg_launch_s / 1e9
         # HBM bytes per launch from the PMC passes under profiles/ -- only when they were collected from these very sources
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath) and modes == [0, 0, 0] and not args.decode and args.signal == 'white':
-            try:
-                pmc = json.load(open(tpath))
-                if pmc.get('source_sha') == source_sha() and dom in pmc:
-                    traffic = pmc[dom]['hbm_bytes_per_launch'] * (frames_per_launch * 2 / pmc['units_per_launch'])
-                    traffic_source = 'profiles/pmc_traffic.json@' + pmc['source_sha']
-                else:
-                    traffic_source = 'profiles/pmc_traffic.json is from other kernel sources (%s): not used' % pmc.get('source_sha')
-            except Exception:   # noqa: BLE001
-                traffic = None
+        if modes == [0, 0, 0] and not args.decode and args.signal == 'white':
+            pmc, traffic_source = load_pmc()
+            sec = (pmc or {}).get('sections', {}).get('config2', {})
+            if dom in sec and sec[dom].get('hbm_bytes_per_launch'):
+                traffic = sec[dom]['hbm_bytes_per_launch'] * (frames_per_launch * 2 / sec['units_per_launch'])
         # what a copy kernel sustains on this box (read + write bytes): the measured-peak denominator SURVEY 8(d) asks for
         a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
         b = torch.empty_like(a)
@@ -331,25 +368,40 @@ def main():
                          'peak_measured_copy': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs,
                          'whole_pass_frac_of_measured_copy': BYTES_PER_STEREO_FRAME * value / world / 1e9 / copy_gbs},
             'kernels_ms_per_step': {k: v['ms_per_step'] for k, v in kernel_ms.items()},
-            'speculation': None if not speculative else {'redo_fraction': redo_fraction, 'units_per_step': 2 * frames},
+            'speculation': None if not speculative else dict(spec_detail, redo_fraction_of_speculated=redo_fraction, units_per_call=2 * frames,
+                                                             note='totals over warm-up and timed steps'),
         }
+        line['roofline_valu'] = valu_roofline(dom, dom_ms / dom_n, frames_per_launch * 2,
+                                              'config2' if (modes == [0, 0, 0] and args.signal == 'white' and not args.decode) else None)
 
     # ------------------------------------------------------------------ config 4's per-GPU share (every rank)
-    if (world > 1 or args.config4) and not args.decode:
+    default_workload = (not args.decode and args.signal == 'white' and modes == [0, 0, 0])
+    if (world > 1 or args.config4 or (default_workload and not args.no_extras and not args.no_config4)) and not args.decode:
         f4 = args.config4_frames
         del pcm, units
         pcm4 = generate(f4, 'mixed', (5, 6), rank * f4)
         o4 = options_for([0, 0, 0], 1.0)
-        units4, el4, km4, redo4, su4 = encode_run(pcm4, f4, o4.to_c(), 1, 1)
-        ok4 = None
+        units4, el4, km4, redo4, su4, det4 = encode_run(pcm4, f4, o4.to_c(), 2, 1)
         if rank == 0:
+            # parity on the very PCM the device holds: 2048 frames from the start (all four segment kinds), and 2048 frames from a
+            # segment boundary deep inside the share, encoded by the oracle from its one-frame halo
             ok4, _ = parity_subset(pcm4, units4, 2048, (0, 0, 0), 1.0)
+            ok4b = None
+            if f4 > 3000000:
+                import oracle_lib as O
+                a0 = (f4 // 2 // 2048) * 2048
+                host = [p[(a0 - 1) * 512:(a0 + 2048) * 512].cpu().numpy() for p in pcm4]
+                st = (O.EncState * 2)()
+                w, _ = O.encode_stream(host, fixed_modes=(0, 0, 0), states=st)
+                ok4b = bool(np.array_equal(units4[a0 * 424:(a0 + 2048) * 424].cpu().numpy().reshape(-1, 212), w[2:]))
             line['config4_share'] = {'workload': 'BASELINE configs[3] share: mixed corpus (white / pink+bursts / partials / quiet white, 512-frame segments), '
                                                  '%d stereo frames per GPU, fixedBlockModes 0,0,0, bias 1' % f4,
-                                     'value': f4 * world / el4, 'unit': 'stereo frames/s', 'n_gpus': world, 'ms': el4 * 1e3,
-                                     'kernels_ms': {k: v['ms_per_step'] for k, v in km4.items()},
-                                     'redo_fraction': redo4, 'speculative_units': su4,
-                                     'parity_first_2048_frames_vs_oracle': ok4}
+                                     'value': f4 * world * 2 / el4, 'unit': 'stereo frames/s', 'n_gpus': world, 'ms_per_pass': el4 / 2 * 1e3, 'passes': 2,
+                                     'kernels_ms_last_pass': {k: v['ms_per_step'] for k, v in km4.items()},
+                                     'whole_pass_frac_of_hbm_peak': BYTES_PER_STEREO_FRAME * (f4 * 2 / el4) / 1e9 / HBM_PEAK_GBS,
+                                     'speculation': dict(det4, redo_fraction_of_speculated=redo4, note='totals over 1 warm-up and 2 timed passes'),
+                                     'parity_first_2048_frames_vs_oracle': ok4,
+                                     'parity_2048_frames_mid_share_vs_oracle': ok4b}
         del pcm4, units4
         pcm = units = None
 
@@ -360,9 +412,9 @@ def main():
         if pcm is None:
             pcm = generate(frames, 'white', (1, 2), 0)
         # headline with the exact kernels only
-        u0, el, km, _, _ = encode_run(pcm, frames, c_opts, 3, 1, spec_mode=0)
+        u0, el, km, _, _, _ = encode_run(pcm, frames, c_opts, 3, 1, spec_mode=0)
         ex['config2_exact_kernels_only'] = {'value': frames * 3 / el, 'kernels_ms_per_step': {k: v['ms_per_step'] for k, v in km.items()}}
-        u1, _, _, _, _ = encode_run(pcm, frames, c_opts, 1, 0, spec_mode=2)
+        u1, _, _, _, _, _ = encode_run(pcm, frames, c_opts, 1, 0, spec_mode=2)
         ex['config2_speculative_equals_exact_bytes'] = bool(torch.equal(u0, u1))
         ok, _ = parity_subset(pcm, u1, 4096, (0, 0, 0), 1.0)
         ex['config2_parity_first_4096_frames_vs_oracle'] = ok
@@ -386,7 +438,7 @@ def main():
         for m5 in ([0, 0, 0], [2, 2, 3]):
             for b5 in (0.5, 1.0, 2.0):
                 o5 = options_for(m5, b5)
-                u5, el, km, redo, su = encode_run(pcm, frames, o5.to_c(), 3, 1)
+                u5, el, km, redo, su, _ = encode_run(pcm, frames, o5.to_c(), 3, 1)
                 ok, _ = parity_subset(pcm, u5, 512, tuple(m5), b5)
                 c5.append({'modes': m5, 'bias': b5, 'value': frames * 3 / el, 'redo_fraction': redo,
                            'kernels_ms_per_step': {k: round(v['ms_per_step'], 3) for k, v in km.items()},
@@ -397,9 +449,9 @@ def main():
         tone = generate(frames, 'partials', (7, 8), 0)
         o_t = options_for([0, 0, 0], 1.0).to_c()
         t = {}
-        for name, mode in (('exact_kernels_only', 0), ('speculation_forced', 2), ('adaptive', 1)):
-            ut, el, km, redo, su = encode_run(tone, frames, o_t, 3, 1, spec_mode=mode)
-            t[name] = {'value': frames * 3 / el, 'redo_fraction': redo}
+        for name, mode in (('exact_kernels_only', 0), ('speculation_forced', 2), ('material_local_default', 1)):
+            ut, el, km, redo, su, dt = encode_run(tone, frames, o_t, 3, 1, spec_mode=mode)
+            t[name] = dict(dt, value=frames * 3 / el, redo_fraction_of_speculated=redo)
             del ut
         ex['tonal_partials_1M_frames'] = t
         del tone, pcm
@@ -411,7 +463,7 @@ def main():
         # untimed warm-up on the first chunk: the detection workspace (4.3 GB per 1 M-frame chunk) is allocated on first use
         wu = encode_run(p3, min(f3, 1 << 20), o3.to_c(), 1, 0)
         del wu
-        u3, el_e, km_e, _, _ = encode_run(p3, f3, o3.to_c(), 1, 0)
+        u3, el_e, km_e, _, _, _ = encode_run(p3, f3, o3.to_c(), 1, 0)
         det_units, det_open = ctx.detection_stats()
         outp = [torch.empty(f3 * 512, dtype=torch.float32, device=dev) for _ in range(2)]
         optr = [p.data_ptr() for p in outp]
@@ -437,6 +489,19 @@ def main():
                          'parity_subset_frames': nsub, 'units_and_block_modes_equal_oracle': ok_units,
                          'decoded_pcm_rms_vs_oracle': rms, 'decoded_pcm_bit_identical_to_oracle': bool(bits),
                          'mid_stream_slice_with_halo_equals_full_run': mid_ok}
+        # both ceilings for config 3's dominant kernel (k_detect_features<true>: exact QMF + binary32 transient FFT), from the counter
+        # passes under profiles/ (same kernel sources only): algorithmic bytes against its profiled launch time, and its vector issue
+        pmc, src = load_pmc()
+        sec = (pmc or {}).get('sections', {}).get('config3', {})
+        if 'analysis' in sec and sec['analysis'].get('profiled_launch_ms'):
+            e = sec['analysis']
+            ach = BYTES_PER_STEREO_FRAME * (sec['units_per_launch'] / 2) / (e['profiled_launch_ms'] * 1e-3) / 1e9
+            ex['config3']['roofline'] = {'bound': 'hbm', 'kernel': e['kernel'], 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                                         'avg_launch_ms': e['profiled_launch_ms'], 'traffic': e.get('hbm_bytes_per_launch'), 'source': src,
+                                         'whole_pass_frac': BYTES_PER_STEREO_FRAME * (f3 / el_e) / 1e9 / HBM_PEAK_GBS}
+            ex['config3']['roofline_valu'] = valu_roofline('analysis', e['profiled_launch_ms'], sec['units_per_launch'], 'config3')
+        else:
+            ex['config3']['roofline_valu'] = {'bound': 'valu', 'frac': None, 'source': src}
         del p3, u3, outp
         # the frame closures of the JavaScript host: one GPU round trip per 512-sample frame (reported, not optimised)
         try:

@@ -28,6 +28,21 @@ SPECS_PER_BFU = (8, 8, 8, 8, 4, 4, 4, 4, 8, 8, 8, 8, 6, 6, 6, 6, 6, 6, 6, 6, 6, 
 WORD_LENGTH_BITS = (0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)
 
 
+_BIASED = None
+
+
+def packaged_biased_table(bias):
+    """pow(SCALE_FACTORS, bias) as V8 computed it, for the biases carta1_amd/biased_tables.json holds; else None"""
+    global _BIASED
+    if _BIASED is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'biased_tables.json')
+        raw = json.load(open(path))['biased_scale_factors_f64']
+        _BIASED = {float(k): [struct.unpack('>d', bytes.fromhex(h))[0] for h in v] for k, v in raw.items()}
+    return _BIASED.get(float(bias))
+
+
 class EncoderOptions:
     """codec/core/options.js: same keys, defaults, ranges and error messages."""
     _RANGES = {'transientThresholdLow': (0.01, 2), 'transientThresholdMid': (0.01, 3),
@@ -57,15 +72,19 @@ class EncoderOptions:
         raise AttributeError(name)
 
     def to_c(self):
-        """c1_encode_options.  The biased table is pow(SCALE_FACTORS[i], bias) (bitallocation.js:46-61);
-        libm's pow equals V8's for bias in {0, 0.5, 1, 2, 5} (tests/golden/tables.json) and may differ in
-        the last bit elsewhere -- pass biased_table to pin it."""
+        """c1_encode_options.  The biased table is pow(SCALE_FACTORS[i], bias) (bitallocation.js:46-61) as the
+        reference's engine computes it; Math.pow is not correctly rounded and differs between engines, so
+        the package carries the tables V8 produced for the biases 0, 0.25, 0.5, 1, 1.5, 2, 3.3 and 5
+        (carta1_amd/biased_tables.json, generated from the golden vectors).  Any other bias falls back to libm's pow,
+        whose last bit may differ from V8's ("parity unpinned" for those) -- pass biased_table to pin it; the JavaScript
+        host always uses its own engine's Math.pow."""
         o = capi.EncodeOptions()
         capi.check(capi.load().c1_default_encode_options(C.byref(o)))
         bias = float(self.values['allocationBias'])
-        if self.biased_table is not None:
+        table = self.biased_table if self.biased_table is not None else packaged_biased_table(bias)
+        if table is not None:
             for i in range(64):
-                o.biased_scale_factors[i] = float(self.biased_table[i])
+                o.biased_scale_factors[i] = float(table[i])
         elif bias != 1.0:
             sf = [o.biased_scale_factors[i] for i in range(64)]
             for i in range(64):

@@ -414,6 +414,17 @@ struct c1_ctx {
   double *d_feat[2] = {nullptr, nullptr};
   uint8_t *d_modes[2] = {nullptr, nullptr};
   uint32_t *d_lists[2] = {nullptr, nullptr};
+  // Tail overlap: the exact redo of a speculative chunk -- short lists, latency-bound launches -- runs on
+  // s_tail while the next chunk's (or, on a context that owns its stream, the next call's) main kernels run on the
+  // context's stream; the two chunks work on different halves of the workspace.  ev_main[p] / ev_tail[p]: main part /
+  // tail of the chunk that last used half p.  tail_pending: a tail is in flight that the context's stream has not
+  // been made to wait for yet (join_tail); every entry point but the device encode joins before it does anything.
+  bool overlap = true;
+  hipStream_t s_tail = nullptr;
+  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+  bool tail_used[2] = {false, false};
+  bool tail_pending = false;
+  int ws_next = 0;
   int64_t chunk_frames = 0;
   bool pipeline = true;
   hipStream_t s_ana = nullptr, s_rest = nullptr;  // internal streams of the two pipeline halves
@@ -441,9 +452,19 @@ namespace {
   std::unique_lock<std::recursive_mutex> ctx_guard_;   \
   if (c) ctx_guard_ = std::unique_lock<std::recursive_mutex>((c)->mu)
 
-int ctx_bind(c1_ctx *ctx) {
+// the context's stream waits for every tail in flight: from here on it sees the finished results of all earlier calls
+int join_tail(c1_ctx *ctx) {
+  if (!ctx->tail_pending) return C1_OK;
+  for (int p = 0; p < 2; p++)
+    if (ctx->tail_used[p]) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
+  ctx->tail_pending = false;
+  return C1_OK;
+}
+
+int ctx_bind(c1_ctx *ctx, bool join = true) {
   if (!ctx) return fail(C1_ERR_ARG, "context is NULL");
   HIP_TRY(hipSetDevice(ctx->device));
+  if (join) return join_tail(ctx);
   return C1_OK;
 }
 
@@ -493,7 +514,9 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
   if (units <= ctx->ws_units) return C1_OK;
   HIP_TRY(hipDeviceSynchronize());
   free_workspace(ctx);
-  for (int p = 0; p < (ctx->pipeline ? 2 : 1); p++) {
+  ctx->tail_used[0] = ctx->tail_used[1] = false;
+  ctx->tail_pending = false;
+  for (int p = 0; p < ((ctx->pipeline || ctx->overlap) ? 2 : 1); p++) {
     HIP_TRY(hipMalloc(&ctx->d_coefs[p], (size_t)units * 512 * sizeof(float)));
     HIP_TRY(hipMalloc(&ctx->d_side[p], (size_t)units * kSideBytes));
     HIP_TRY(hipMalloc(&ctx->d_alloc[p], (size_t)units * kAllocBytes));
@@ -537,7 +560,9 @@ int upload_opts(c1_ctx *ctx, const c1_encode_options *opts) {
   C1DevEncOpts h;
   const int rc = build_encode_opts(*opts, &h);
   if (rc) return rc;
-  // the previous options may still be in use by kernels queued on the stream
+  // the previous options may still be in use by kernels queued on the stream (or on the tail stream)
+  int jr = join_tail(ctx);
+  if (jr) return jr;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(ctx->d_opts, &h, sizeof h, hipMemcpyHostToDevice));
   ctx->last_opts = *opts;
@@ -580,6 +605,8 @@ void reset_timings(c1_ctx *ctx) {
 }
 int collect_timings(c1_ctx *ctx) {
   if (ctx->timings.empty()) return C1_OK;
+  int jr = join_tail(ctx);
+  if (jr) return jr;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (auto &t : ctx->timings) {
     float ms = 0;
@@ -598,11 +625,13 @@ int check_channels(int channels) {
   return C1_OK;
 }
 
+// lazy: the call may return with its last tail still unjoined (c1_encode_device on a context that owns its stream: nobody
+// else can enqueue on that stream, and every other entry point joins first)
 int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                        const c1_encode_options *opts, uint8_t *units, float *bands, float *coefs_tap,
-                       uint8_t *side_tap, uint8_t *alloc_tap) {
+                       uint8_t *side_tap, uint8_t *alloc_tap, bool lazy = false) {
   CTX_GUARD(ctx);
-  int rc = ctx_bind(ctx);
+  int rc = ctx_bind(ctx, false);
   if (rc) return rc;
   if ((rc = check_channels(channels))) return rc;
   if (frames < 0) return fail(C1_ERR_ARG, "frames must be >= 0");
@@ -653,6 +682,8 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     // binary32 too, unit by unit.)
     if (!speculate && ctx->q32_last_fraction > 0.10 && ctx->q32_off_calls < 15) { quantize32 = false; ctx->q32_off_calls++; }
   }
+  const bool overlap = speculate && ctx->overlap && ctx->s_tail != nullptr;
+  if (!overlap && (rc = join_tail(ctx))) return rc;       // every other path works on the context's stream alone
   const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate;
   hipStream_t sA = piped ? ctx->s_ana : ctx->stream, sB = piped ? ctx->s_rest : ctx->stream;
   if (piped) {
@@ -663,7 +694,8 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   int64_t index = 0;
   for (int64_t f0 = 0, n = 0; f0 < frames; f0 += n, ++index) {
     n = taps ? frames : std::min(chunk, frames - f0);
-    const int p = piped ? (int)(index & 1) : 0;
+    int p = piped ? (int)(index & 1) : 0;
+    if (overlap) { p = ctx->ws_next; ctx->ws_next ^= 1; }
     C1EncodeLaunch L;
     memset(&L, 0, sizeof L);
     for (int c = 0; c < channels; c++) L.pcm[c] = pcm[c] + f0 * 512;
@@ -693,6 +725,8 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       L.eps = ctx->d_eps[p];
       bind_lists(ctx, p, &L);
       if (ctx->spec_mode == 1) { bind_defer(ctx, p, &L); L.spec_defer = ctx->spec_defer; }
+      // this half of the workspace is free once the tail of the chunk that used it last is through
+      if (overlap && ctx->tail_used[p]) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_tail[p], 0));
       HIP_TRY(hipMemsetAsync(ctx->d_redo[p], 0, kListHead * sizeof(uint32_t), sA));
       {
         ScopedTiming t(ctx, K_ANALYSIS, sA);
@@ -709,9 +743,20 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
         }
       }
       { ScopedTiming t(ctx, K_ALLOCATE, sA); c1k_launch_allocate(L, sA); }
+      // The previous chunk's tail repacks units of ITS output range; when a caller reuses one output buffer call after
+      // call that range is this chunk's: the tail's stores must have landed before this chunk packs (in practice it
+      // finished long ago: it has had the whole analysis and allocation of this chunk to run beside)
+      if (overlap && ctx->tail_used[p ^ 1]) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_tail[p ^ 1], 0));
       { ScopedTiming t(ctx, K_PACK, sA); c1k_launch_pack_spec(L, all_long_modes, sA); }
+      hipStream_t sT = sA;
+      if (overlap) {
+        sT = ctx->s_tail;
+        HIP_TRY(hipEventRecord(ctx->ev_main[p], sA));
+        HIP_TRY(hipStreamWaitEvent(sT, ctx->ev_main[p], 0));
+      }
       {
-        ScopedTiming t(ctx, K_REDO, sA);
+        ScopedTiming t(ctx, K_REDO, sT);
+        hipStream_t sA = sT;                                   // the exact redo of the listed units: on the tail stream
         C1EncodeLaunch R = L;
         R.defer_list = nullptr;
         R.unit_list = L.reana_list;
@@ -725,6 +770,11 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
         R.unit_count = L.redo_count;
         c1k_launch_pack(R, all_long_modes, sA);
         c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), ctx->d_redo[p], 0, sA);
+      }
+      if (overlap) {
+        HIP_TRY(hipEventRecord(ctx->ev_tail[p], sT));
+        ctx->tail_used[p] = true;
+        ctx->tail_pending = true;
       }
       continue;
     }
@@ -769,6 +819,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_end[0], 0));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_end[1], 0));
   }
+  if (overlap && !lazy && (rc = join_tail(ctx))) return rc;
   HIP_TRY(hipGetLastError());
   return C1_OK;
 }
@@ -920,6 +971,14 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&ctx->ev_end[p], hipEventDisableTiming);
     }
     if (pe != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "pipeline streams: %s", hipGetErrorString(pe)); }
+    if (pe == hipSuccess) pe = hipStreamCreateWithFlags(&ctx->s_tail, hipStreamNonBlocking);
+    for (int p = 0; p < 2 && pe == hipSuccess; p++) {
+      pe = hipEventCreateWithFlags(&ctx->ev_main[p], hipEventDisableTiming);
+      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&ctx->ev_tail[p], hipEventDisableTiming);
+    }
+    if (pe != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "tail stream: %s", hipGetErrorString(pe)); }
+    const char *ov = getenv("C1_OVERLAP");      // experiments: 0 = the exact redo on the context's stream, in line
+    ctx->overlap = ov ? atoi(ov) != 0 : true;
     const char *pl = getenv("C1_PIPELINE");
     ctx->pipeline = pl ? atoi(pl) != 0 : false;   // measured: no gain while one kernel's grid already owns every CU's LDS
   }
@@ -936,6 +995,7 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
 int c1_ctx_destroy(c1_ctx *ctx) {
   if (!ctx) return C1_OK;
   hipSetDevice(ctx->device);
+  if (ctx->s_tail) hipStreamSynchronize(ctx->s_tail);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   for (auto &t : ctx->timings) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto e : ctx->event_pool) hipEventDestroy(e);
@@ -945,6 +1005,11 @@ int c1_ctx_destroy(c1_ctx *ctx) {
   if (ctx->h_totals) (void)hipHostFree(const_cast<unsigned long long *>(ctx->h_totals));
   (void)hipDeviceSynchronize();
   free_workspace(ctx);
+  if (ctx->s_tail) (void)hipStreamDestroy(ctx->s_tail);
+  for (int p = 0; p < 2; p++) {
+    if (ctx->ev_main[p]) (void)hipEventDestroy(ctx->ev_main[p]);
+    if (ctx->ev_tail[p]) (void)hipEventDestroy(ctx->ev_tail[p]);
+  }
   if (ctx->s_ana) (void)hipStreamDestroy(ctx->s_ana);
   if (ctx->s_rest) (void)hipStreamDestroy(ctx->s_rest);
   if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
@@ -1083,7 +1148,15 @@ int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches) {
 int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
                      const c1_encode_options *opts, uint8_t *units) {
   if (!units && frames > 0) return fail(C1_ERR_ARG, "units is NULL");
-  return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, units, nullptr, nullptr, nullptr, nullptr);
+  // On a context that owns its stream the last chunk's exact redo may still be running on the tail stream when the call
+  // returns: it overlaps the next call's analysis.  c1_ctx_synchronize and every other entry point wait for it.
+  return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, units, nullptr, nullptr, nullptr, nullptr, ctx && ctx->own_stream);
+}
+// for the host-resident entry points below: ordered like any other work on the context's stream
+static int encode_device_joined(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
+                                const c1_encode_options *opts, uint8_t *units) {
+  if (!units && frames > 0) return fail(C1_ERR_ARG, "units is NULL");
+  return encode_device_impl(ctx, pcm, channels, frames, halo_frames, opts, units, nullptr, nullptr, nullptr, nullptr, false);
 }
 
 int c1_encode_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames, int halo_frames,
@@ -1367,7 +1440,7 @@ int encode_batch_streamed(c1_ctx *ctx, const float *const *pcm, int channels, in
     HIP_TRY(hipEventRecord(ctx->ev_up[p], ctx->s_up));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[p], 0));
     uint8_t *d_units = reinterpret_cast<uint8_t *>(set + in_bytes * channels);
-    if ((rc = c1_encode_device(ctx, dptr, channels, n, h, opts, d_units))) return rc;
+    if ((rc = encode_device_joined(ctx, dptr, channels, n, h, opts, d_units))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_run[p], ctx->stream));
     if (index >= 1 && (rc = download(index - 1))) return rc;
   }
@@ -1467,7 +1540,7 @@ int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t 
     dptr[c] = d + (size_t)halo_frames * 512;
   }
   uint8_t *d_units = (uint8_t *)ctx->d_io + unit_off;
-  if ((rc = c1_encode_device(ctx, dptr, channels, frames, halo_frames, opts, d_units))) return rc;
+  if ((rc = encode_device_joined(ctx, dptr, channels, frames, halo_frames, opts, d_units))) return rc;
   HIP_TRY(hipMemcpyAsync(units, d_units, unit_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return C1_OK;
@@ -1691,7 +1764,7 @@ int c1_encode_wav_batch(c1_ctx *ctx, const void *interleaved, int bits, int chan
         HIP_TRY(hipMemsetAsync(dch[c] + have, 0, (size_t)((n + h) * 512 - have) * sizeof(float), ctx->stream));
     }
     c1k_launch_pcm_from_int(set, bits, channels, have, dch, ctx->stream);
-    if ((rc = c1_encode_device(ctx, dptr, channels, n, h, opts, reinterpret_cast<uint8_t *>(set + raw_bytes + pcm_bytes * channels)))) return rc;
+    if ((rc = encode_device_joined(ctx, dptr, channels, n, h, opts, reinterpret_cast<uint8_t *>(set + raw_bytes + pcm_bytes * channels)))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_run[p], ctx->stream));
     if (index >= 1 && (rc = download(index - 1))) return rc;
   }
@@ -1810,7 +1883,7 @@ int c1_enc_stream_push(c1_enc_stream *s, const float *const *pcm, int64_t frames
     HIP_TRY(hipMemcpyAsync(d + 1024, pcm[c], (size_t)frames * 512 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     dptr[c] = d + 1024;
   }
-  if ((rc = c1_encode_device(ctx, dptr, s->channels, frames, 2, &s->opts, s->d_units))) return rc;
+  if ((rc = encode_device_joined(ctx, dptr, s->channels, frames, 2, &s->opts, s->d_units))) return rc;
   for (int c = 0; c < s->channels; c++)   // new history = the last two frames of [history | pushed]
     HIP_TRY(hipMemcpyAsync(s->d_hist + 1024 * c, s->d_buf + stride * c + (size_t)frames * 512, 1024 * sizeof(float),
                            hipMemcpyDeviceToDevice, ctx->stream));
