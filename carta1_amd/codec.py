@@ -294,6 +294,51 @@ class Context:
             self._h, capi.ptr_array(pcm_ptrs), len(pcm_ptrs), frames, halo_frames, C.byref(opts),
             C.c_void_p(coefs_ptr), C.c_void_p(eps_ptr), C.c_void_p(side_ptr)))
 
+    # ---- the single-stage functions the reference exports (codec/index.js:30-35,42), host arrays ----------------
+    def quantize(self, coefficients, scale_factor_index, bits_per_sample):
+        """quantize, codec/coding/quantization.js:34-56 -> int32 array"""
+        x = np.ascontiguousarray(coefficients, dtype=np.float32)
+        out = np.zeros(x.size, dtype=np.int32)
+        capi.check(capi.load().c1_quantize(self._h, x.ctypes.data, x.size, int(scale_factor_index), int(bits_per_sample), out.ctypes.data))
+        return out
+
+    def dequantize(self, quantized, scale_factor_index, bits_per_sample):
+        """dequantize, quantization.js:65-78 -> float32 array"""
+        q = np.ascontiguousarray(quantized, dtype=np.int32)
+        out = np.zeros(q.size, dtype=np.float32)
+        capi.check(capi.load().c1_dequantize(self._h, q.ctypes.data, q.size, int(scale_factor_index), int(bits_per_sample), out.ctypes.data))
+        return out
+
+    def fft(self, real, imag, w):
+        """FFT.fft, codec/transforms/fft.js:14-68, in place on two contiguous float32 arrays; w: (cos, sin)(-2 pi / stride) for
+        stride = 2, 4, .., n as the reference's engine computes them (float64, log2(n) pairs)"""
+        if real.dtype != np.float32 or imag.dtype != np.float32 or not real.flags['C_CONTIGUOUS'] or not imag.flags['C_CONTIGUOUS'] or real.size != imag.size:
+            raise ValueError('fft works in place on two contiguous float32 arrays of equal length')
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        capi.check(capi.load().c1_fft(self._h, real.ctypes.data, imag.ctypes.data, real.size, w.ctypes.data))
+
+    def qmf_analysis(self, pcm, halo_frames=0):
+        """qmfAnalysisStage, codec/pipeline/encoder.js:57-96: pcm = (halo_frames + frames) * 512 samples of one channel
+        -> float32 [frames, 512] (low128 | mid128 | high256)"""
+        x = np.ascontiguousarray(pcm, dtype=np.float32)
+        frames = x.size // 512 - halo_frames
+        out = np.zeros((max(frames, 0), 512), dtype=np.float32)
+        capi.check(capi.load().c1_qmf_analysis_batch(self._h, x.ctypes.data, frames, halo_frames, out.ctypes.data))
+        return out
+
+    def mdct(self, bands, block_modes, halo_frames=0):
+        """mdctStage, encoder.js:170-349: bands float32 [(halo_frames + frames), 512], block_modes int [frames, 3]
+        -> (coefficients [frames, 512], the bands as the reference leaves them [frames, 512])"""
+        b = np.ascontiguousarray(bands, dtype=np.float32).reshape(-1, 512)
+        frames = b.shape[0] - halo_frames
+        m = np.ascontiguousarray(block_modes, dtype=np.int32).reshape(-1)
+        if m.size != 3 * frames:
+            raise ValueError('block_modes must hold three entries per frame')
+        co = np.zeros((frames, 512), dtype=np.float32)
+        bw = np.zeros((frames, 512), dtype=np.float32)
+        capi.check(capi.load().c1_mdct_batch(self._h, b.ctypes.data, frames, halo_frames, m.ctypes.data, co.ctypes.data, bw.ctypes.data))
+        return co, bw
+
     def pack_spec_tap_device(self, coefs_ptr, eps_ptr, side_ptr, alloc_ptr, units, units_out_ptr, lists_ptr, all_long=True):
         """Test tap: the speculative quantizer + packer on caller-supplied coefficients, bounds and records (device pointers)."""
         capi.check(capi.load().c1_pack_spec_tap_device(

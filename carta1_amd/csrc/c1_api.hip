@@ -850,6 +850,20 @@ XsMatrix xs_power(uint64_t n) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
+namespace {
+struct DeviceScratch {       // a few small device buffers for one call, freed on every path
+  std::vector<void *> ptrs;
+  ~DeviceScratch() { for (void *p : ptrs) (void)hipFree(p); }
+  template <class T> int alloc(T **out, size_t count) {
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return fail(C1_ERR_HIP, "device allocation of %zu bytes failed", count * sizeof(T));
+    ptrs.push_back(p);
+    *out = static_cast<T *>(p);
+    return C1_OK;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 int c1_abi_version(void) { return C1_ABI_VERSION; }
@@ -1323,6 +1337,132 @@ int c1_spec_stages_device(c1_ctx *ctx, const float *const *pcm, int channels, in
   L.tables = ctx->d_tables; L.opts = ctx->d_opts;
   L.coefs = coefs; L.eps = eps; L.side = side;
   c1k_launch_analysis_spec(L, sp_short, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  return C1_OK;
+}
+
+// ---- the single-stage functions of the reference's export surface (codec/index.js:30-35,42), host-resident ----------
+
+int c1_quantize(c1_ctx *ctx, const float *coefficients, int n, int scale_factor_index, int bits_per_sample, int32_t *out) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!coefficients || !out))) return fail(C1_ERR_ARG, "quantize: bad arguments");
+  if (scale_factor_index < 0 || scale_factor_index > 63) return fail(C1_ERR_ARG, "quantize: scaleFactorIndex %d outside SCALE_FACTORS", scale_factor_index);
+  if (bits_per_sample < 0 || bits_per_sample > 32) return fail(C1_ERR_ARG, "quantize: bitsPerSample %d", bits_per_sample);
+  if (n == 0) return C1_OK;
+  DeviceScratch ds;
+  float *dx; int32_t *dq;
+  if ((rc = ds.alloc(&dx, (size_t)n)) || (rc = ds.alloc(&dq, (size_t)n))) return rc;
+  HIP_TRY(hipMemcpyAsync(dx, coefficients, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  c1k_launch_quantize_one(ctx->d_tables, dx, n, scale_factor_index, bits_per_sample, dq, ctx->stream);
+  HIP_TRY(hipMemcpyAsync(out, dq, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_dequantize(c1_ctx *ctx, const int32_t *quantized, int n, int scale_factor_index, int bits_per_sample, float *out) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!quantized || !out))) return fail(C1_ERR_ARG, "dequantize: bad arguments");
+  if (scale_factor_index < 0 || scale_factor_index > 63) return fail(C1_ERR_ARG, "dequantize: scaleFactorIndex %d outside SCALE_FACTORS", scale_factor_index);
+  if (bits_per_sample < 0 || bits_per_sample > 32) return fail(C1_ERR_ARG, "dequantize: bitsPerSample %d", bits_per_sample);
+  if (n == 0) return C1_OK;
+  DeviceScratch ds;
+  int32_t *dq; float *dx;
+  if ((rc = ds.alloc(&dq, (size_t)n)) || (rc = ds.alloc(&dx, (size_t)n))) return rc;
+  HIP_TRY(hipMemcpyAsync(dq, quantized, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  c1k_launch_dequantize_one(ctx->d_tables, dq, n, scale_factor_index, bits_per_sample, dx, ctx->stream);
+  HIP_TRY(hipMemcpyAsync(out, dx, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_fft(c1_ctx *ctx, float *real, float *imag, int n, const double *w) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (n < 1 || (n & (n - 1)) || n > (1 << 22)) return fail(C1_ERR_ARG, "fft: size must be a power of two <= 2^22, got %d", n);
+  if (!real || !imag || (n > 1 && !w)) return fail(C1_ERR_ARG, "fft: NULL argument");
+  if (n == 1) return C1_OK;                                  // fft.js:16
+  int stages = 0;
+  while ((1 << stages) < n) stages++;
+  DeviceScratch ds;
+  float *dr, *di; double *dw, *dtw;
+  if ((rc = ds.alloc(&dr, (size_t)n)) || (rc = ds.alloc(&di, (size_t)n)) || (rc = ds.alloc(&dw, (size_t)2 * stages)) || (rc = ds.alloc(&dtw, (size_t)n))) return rc;
+  HIP_TRY(hipMemcpyAsync(dr, real, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(di, imag, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dw, w, (size_t)2 * stages * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  c1k_launch_fft_reference(dr, di, n, dw, dtw, ctx->stream);
+  HIP_TRY(hipMemcpyAsync(real, dr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(imag, di, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_qmf_analysis_batch(c1_ctx *ctx, const float *pcm, int64_t frames, int halo_frames, float *bands) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "qmf analysis: bad frames / halo_frames");
+  if (frames == 0) return C1_OK;
+  if (!pcm || !bands) return fail(C1_ERR_ARG, "qmf analysis: NULL argument");
+  if (frames > (1 << 20)) return fail(C1_ERR_ARG, "qmf analysis: at most 2^20 frames per call");
+  DeviceScratch ds;
+  float *dp, *db, *dc; uint8_t *dside, *dalloc;
+  const size_t total = (size_t)(frames + halo_frames) * 512;
+  if ((rc = ds.alloc(&dp, total)) || (rc = ds.alloc(&db, (size_t)frames * 512)) || (rc = ds.alloc(&dc, (size_t)frames * 512)) ||
+      (rc = ds.alloc(&dside, (size_t)frames * kSideBytes)) || (rc = ds.alloc(&dalloc, (size_t)frames * kAllocBytes))) return rc;
+  HIP_TRY(hipMemcpyAsync(dp, pcm, total * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  c1_encode_options o;
+  c1_default_encode_options(&o);
+  o.fixed_block_modes[0] = o.fixed_block_modes[1] = o.fixed_block_modes[2] = 0;   // the bands do not depend on the block modes
+  const float *chan[1] = {dp + (size_t)halo_frames * 512};
+  if ((rc = encode_device_impl(ctx, chan, 1, frames, halo_frames, &o, nullptr, db, dc, dside, dalloc))) return rc;
+  HIP_TRY(hipMemcpyAsync(bands, db, (size_t)frames * 512 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return C1_OK;
+}
+
+int c1_mdct_batch(c1_ctx *ctx, const float *bands, int64_t frames, int halo_frames, const int32_t *block_modes, float *coefs,
+                  float *bands_windowed) {
+  CTX_GUARD(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (frames < 0 || halo_frames < 0 || halo_frames > 1) return fail(C1_ERR_ARG, "mdct: halo_frames must be 0 or 1");
+  if (frames == 0) return C1_OK;
+  if (!bands || !block_modes || !coefs) return fail(C1_ERR_ARG, "mdct: NULL argument");
+  if (frames > (1 << 20)) return fail(C1_ERR_ARG, "mdct: at most 2^20 frames per call");
+  // any non-zero mode is a short band (encoder.js:196); the unit header's values are 2, 2, 3
+  std::vector<uint8_t> modes((size_t)frames);
+  std::vector<uint32_t> lists(4 + 2 * (size_t)frames, 0u);
+  for (int64_t f = 0; f < frames; f++) {
+    const int m0 = block_modes[3 * f] ? 2 : 0, m1 = block_modes[3 * f + 1] ? 2 : 0, m2 = block_modes[3 * f + 2] ? 3 : 0;
+    modes[(size_t)f] = (uint8_t)(m0 | (m1 << 2) | (m2 << 4));
+    if (modes[(size_t)f] == 0) lists[4 + lists[0]++] = (uint32_t)f;
+    else lists[4 + (size_t)frames + lists[1]++] = (uint32_t)f;
+  }
+  DeviceScratch ds;
+  float *db, *dc, *dw = nullptr; uint8_t *dm, *dside; uint32_t *dl;
+  if ((rc = ds.alloc(&db, (size_t)(frames + 1) * 512)) || (rc = ds.alloc(&dc, (size_t)frames * 512)) || (rc = ds.alloc(&dm, (size_t)frames)) ||
+      (rc = ds.alloc(&dside, (size_t)frames * kSideBytes)) || (rc = ds.alloc(&dl, lists.size()))) return rc;
+  if (bands_windowed && (rc = ds.alloc(&dw, (size_t)frames * 512))) return rc;
+  // slot row 0 = frame -1: the halo frame, or nothing (a fresh BufferPool's zero overlap, buffers.js:44-48)
+  if (!halo_frames) HIP_TRY(hipMemsetAsync(db, 0, 512 * sizeof(float), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(db + (halo_frames ? 0 : 512), bands, (size_t)(frames + halo_frames) * 512 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dm, modes.data(), modes.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dl, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  C1EncodeLaunch L;
+  memset(&L, 0, sizeof L);
+  L.channels = 1; L.frames = frames; L.halo_frames = halo_frames;
+  L.tables = ctx->d_tables; L.opts = ctx->d_opts;
+  L.coefs = dc; L.side = dside;
+  c1k_launch_mdct_bands(L, db, dm, dl, ctx->stream);
+  if (dw) c1k_launch_window_bands(db + 512, dm, frames, ctx->d_tables, dw, ctx->stream);
+  HIP_TRY(hipMemcpyAsync(coefs, dc, (size_t)frames * 512 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (dw) HIP_TRY(hipMemcpyAsync(bands_windowed, dw, (size_t)frames * 512 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));       // also: the host vectors above outlive the copies
   HIP_TRY(hipGetLastError());
   return C1_OK;
 }

@@ -94,6 +94,23 @@ __device__ __forceinline__ int bfu_of_slot(int p) {
 
 __device__ __forceinline__ float f32(double x) { return (float)x; }  // Float32Array store
 
+// ECMAScript ToInt32 of a double (what `| 0` does): truncate, wrap modulo 2^32.
+__device__ __forceinline__ int32_t to_int32(double x) {
+  const double t = trunc(x);
+  if (fabs(t) < 2147483648.0) return (int32_t)t;
+  const uint64_t bits = (uint64_t)__double_as_longlong(t);
+  const int e = (int)((bits >> 52) & 0x7ff);
+  if (e == 0x7ff) return 0;                                  // NaN, +-Infinity -> 0
+  const int sh = e - 1075;                                   // value = mant * 2^sh, sh >= -21 here
+  const uint64_t mant = (bits & 0xfffffffffffffull) | (1ull << 52);
+  uint32_t low;
+  if (sh >= 32) low = 0u;
+  else if (sh >= 0) low = (uint32_t)(mant << sh);
+  else low = (uint32_t)(mant >> (-sh));
+  return (int32_t)((bits >> 63) ? (0u - low) : low);
+}
+
+
 // index of double element e in a QMF work buffer: 2 pad doubles after every 2^S, so that the 16-byte
 // window reads of a wave whose lanes are 64 bytes (4 outputs per lane, S = 3) or 32 bytes (2 outputs
 // per lane, S = 2) apart are bank-conflict free (tools/lds_model.py); the generic kernels use S = 5

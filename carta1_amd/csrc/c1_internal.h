@@ -170,6 +170,14 @@ constexpr int kFeatureWsDoubles = 20;
 // score_tap (tests): units * 3 * 2 doubles {lo, hi} (speculative) or {score, score}.  L.coefs null: decisions only.
 void c1k_launch_detect(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
                        bool speculative, double *score_tap, hipStream_t stream);
+// mdctStage + scale factors from stored band samples (k_mdct_bands): bands_ws (units + channels) * 512 floats with slot row 0 =
+// frame -1, modes_ws one byte per unit, lists_ws = {count all-long, count mixed, -, -} then the two unit lists, `units` entries apart
+void c1k_launch_mdct_bands(const C1EncodeLaunch &L, const float *bands_ws, const uint8_t *modes_ws, const uint32_t *lists_ws, hipStream_t stream);
+// the single-stage functions the reference exports next to encode()/decode() (c1_k_stages.hip); device pointers
+void c1k_launch_quantize_one(const C1DevTables *tables, const float *x, int n, int sfi, int bits, int32_t *out, hipStream_t stream);
+void c1k_launch_dequantize_one(const C1DevTables *tables, const int32_t *q, int n, int sfi, int bits, float *out, hipStream_t stream);
+void c1k_launch_fft_reference(float *real, float *imag, int n, const double *w, double *twiddle_scratch /* n doubles */, hipStream_t stream);
+void c1k_launch_window_bands(const float *bands, const uint8_t *modes, int64_t units, const C1DevTables *tables, float *out, hipStream_t stream);
 void c1k_launch_detect_spec_tap(const C1EncodeLaunch &L, float *bands_ws, double *feat_ws, hipStream_t stream);   // L.mags, L.mag_bounds
 void c1k_launch_libm(int fn, const double *in, double *out, int64_t n, hipStream_t stream);
 void c1k_launch_log2f_error(uint32_t first, uint64_t count, unsigned long long *out, hipStream_t stream);   // out: 2 x u64 on the device

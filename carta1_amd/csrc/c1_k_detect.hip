@@ -980,6 +980,13 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
 
 }  // namespace
 
+void c1k_launch_mdct_bands(const C1EncodeLaunch &L, const float *bands_ws, const uint8_t *modes_ws, const uint32_t *lists_ws, hipStream_t stream) {
+  const int64_t units = L.frames * L.channels;
+  const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
+  hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+  hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+}
+
 void c1k_launch_detect(const C1EncodeLaunch &L0, float *bands_ws, double *feat_ws, uint8_t *modes_ws, uint32_t *lists_ws,
                        bool speculative, double *score_tap, hipStream_t stream) {
   static const int slots = c1k_wave_slots(k_detect_features<false>);

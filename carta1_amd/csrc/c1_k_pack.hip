@@ -6,22 +6,6 @@ namespace {
 // =====================================================================================================
 // k_pack : quantize (quantization.js:34-56) + serializeFrame (serialization.js:41-98)
 // =====================================================================================================
-// ECMAScript ToInt32 of a double (what `| 0` does): truncate, wrap modulo 2^32.
-__device__ __forceinline__ int32_t to_int32(double x) {
-  const double t = trunc(x);
-  if (fabs(t) < 2147483648.0) return (int32_t)t;
-  const uint64_t bits = (uint64_t)__double_as_longlong(t);
-  const int e = (int)((bits >> 52) & 0x7ff);
-  if (e == 0x7ff) return 0;                                  // NaN, +-Infinity -> 0
-  const int sh = e - 1075;                                   // value = mant * 2^sh, sh >= -21 here
-  const uint64_t mant = (bits & 0xfffffffffffffull) | (1ull << 52);
-  uint32_t low;
-  if (sh >= 32) low = 0u;
-  else if (sh >= 0) low = (uint32_t)(mant << sh);
-  else low = (uint32_t)(mant >> (-sh));
-  return (int32_t)((bits >> 63) ? (0u - low) : low);
-}
-
 __device__ __forceinline__ void put_bits_be(uint32_t *words, int pos, uint32_t v, int nbits) {
   // MSB-first (bitstream.js:15-40); words are big-endian 32-bit groups, assembled with LDS atomics
   const int w = pos >> 5, o = pos & 31;

@@ -389,6 +389,23 @@ bool get_ctx_or_devices(napi_env env, napi_value v, AsyncJob *j) {
   }
   return true;
 }
+// keep `v` alive until the job is done; false (and an exception) when the engine cannot reference it -- the job must
+// then not start: its buffers could be collected under it
+bool keep_alive(napi_env env, AsyncJob *j, napi_value v) {
+  napi_ref r = nullptr;
+  if (napi_create_reference(env, v, 1, &r) != napi_ok || !r) {
+    napi_throw_error(env, nullptr, "carta1: cannot reference an argument of the asynchronous call");
+    return false;
+  }
+  j->keep[j->nkeep++] = r;
+  return true;
+}
+void drop_job(napi_env env, AsyncJob *j) {
+  for (int i = 0; i < j->nkeep; i++) if (j->keep[i]) napi_delete_reference(env, j->keep[i]);
+  if (j->result) napi_delete_reference(env, j->result);
+  delete j;
+}
+
 napi_value EncodeBatchAsync(napi_env env, napi_callback_info info) {
   napi_value argv[4];
   if (!get_args(env, info, 4, argv)) return nullptr;
@@ -416,9 +433,9 @@ napi_value EncodeBatchAsync(napi_env env, napi_callback_info info) {
     napi_throw_error(env, nullptr, "could not allocate the result");
     return nullptr;
   }
-  napi_create_reference(env, argv[0], 1, &j->keep[j->nkeep++]);   // the context must outlive the job
-  napi_create_reference(env, argv[1], 1, &j->keep[j->nkeep++]);
-  napi_create_reference(env, out, 1, &j->result);
+  // the context (or device list) and the input arrays must outlive the job
+  if (!keep_alive(env, j, argv[0]) || !keep_alive(env, j, argv[1])) { drop_job(env, j); return nullptr; }
+  if (napi_create_reference(env, out, 1, &j->result) != napi_ok) { j->result = nullptr; drop_job(env, j); napi_throw_error(env, nullptr, "carta1: cannot reference the result"); return nullptr; }
   return start_job(env, j, "carta1.encodeBatch");
 }
 napi_value DecodeBatchAsync(napi_env env, napi_callback_info info) {
@@ -454,9 +471,8 @@ napi_value DecodeBatchAsync(napi_env env, napi_callback_info info) {
     }
     napi_set_element(env, arr, c, ta);
   }
-  napi_create_reference(env, argv[0], 1, &j->keep[j->nkeep++]);   // the context must outlive the job
-  napi_create_reference(env, argv[1], 1, &j->keep[j->nkeep++]);
-  napi_create_reference(env, arr, 1, &j->result);
+  if (!keep_alive(env, j, argv[0]) || !keep_alive(env, j, argv[1])) { drop_job(env, j); return nullptr; }   // context and units outlive the job
+  if (napi_create_reference(env, arr, 1, &j->result) != napi_ok) { j->result = nullptr; drop_job(env, j); napi_throw_error(env, nullptr, "carta1: cannot reference the result"); return nullptr; }
   return start_job(env, j, "carta1.decodeBatch");
 }
 
@@ -537,6 +553,82 @@ napi_value DecStreamPush(napi_env env, napi_callback_info info) {
   return arr;
 }
 
+// ---- the single-stage functions of the reference's export surface (codec/index.js:30-35,42) ---------------------------
+napi_value Quantize(napi_env env, napi_callback_info info) {      // (ctx, Float32Array, sfi, bits) -> Int32Array
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  c1_ctx *ctx; void *d; size_t n; int32_t sfi = 0, bits = 0;
+  if (!get_external(env, argv[0], &ctx) || !get_typed(env, argv[1], napi_float32_array, &d, &n)) return nullptr;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &sfi));
+  NAPI_OK(napi_get_value_int32(env, argv[3], &bits));
+  napi_value ab, ta; void *q;
+  NAPI_OK(napi_create_arraybuffer(env, n * 4, &q, &ab));
+  NAPI_OK(napi_create_typedarray(env, napi_int32_array, n, ab, 0, &ta));
+  const int rc = c1_quantize(ctx, static_cast<const float *>(d), (int)n, sfi, bits, static_cast<int32_t *>(q));
+  if (rc) return throw_c1(env, rc);
+  return ta;
+}
+napi_value Dequantize(napi_env env, napi_callback_info info) {    // (ctx, Int32Array, sfi, bits) -> Float32Array
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  c1_ctx *ctx; void *d; size_t n; int32_t sfi = 0, bits = 0;
+  if (!get_external(env, argv[0], &ctx) || !get_typed(env, argv[1], napi_int32_array, &d, &n)) return nullptr;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &sfi));
+  NAPI_OK(napi_get_value_int32(env, argv[3], &bits));
+  float *x;
+  napi_value out = make_f32(env, n, &x);
+  const int rc = c1_dequantize(ctx, static_cast<const int32_t *>(d), (int)n, sfi, bits, x);
+  if (rc) return throw_c1(env, rc);
+  return out;
+}
+napi_value Fft(napi_env env, napi_callback_info info) {           // (ctx, real, imag, Float64Array w) in place
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  c1_ctx *ctx; void *re, *im, *w; size_t n, n2, nw;
+  if (!get_external(env, argv[0], &ctx) || !get_typed(env, argv[1], napi_float32_array, &re, &n) ||
+      !get_typed(env, argv[2], napi_float32_array, &im, &n2) || !get_typed(env, argv[3], napi_float64_array, &w, &nw)) return nullptr;
+  size_t stages = 0;
+  while (((size_t)1 << stages) < n) stages++;
+  if (n2 != n || nw < 2 * stages) { napi_throw_type_error(env, nullptr, "fft: real, imag of equal length and log2(n) twiddle pairs"); return nullptr; }
+  const int rc = c1_fft(ctx, static_cast<float *>(re), static_cast<float *>(im), (int)n, static_cast<const double *>(w));
+  if (rc) return throw_c1(env, rc);
+  napi_value undef;
+  napi_get_undefined(env, &undef);
+  return undef;
+}
+napi_value QmfAnalysis(napi_env env, napi_callback_info info) {   // (ctx, Float32Array pcm incl. halo, haloFrames) -> Float32Array bands
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  c1_ctx *ctx; void *d; size_t n; int32_t halo = 0;
+  if (!get_external(env, argv[0], &ctx) || !get_typed(env, argv[1], napi_float32_array, &d, &n)) return nullptr;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &halo));
+  if (n % 512 || halo < 0 || (size_t)halo > n / 512) { napi_throw_type_error(env, nullptr, "qmfAnalysis: whole frames of 512 samples"); return nullptr; }
+  const int64_t frames = (int64_t)(n / 512) - halo;
+  float *b;
+  napi_value out = make_f32(env, (size_t)frames * 512, &b);
+  const int rc = c1_qmf_analysis_batch(ctx, static_cast<const float *>(d), frames, halo, b);
+  if (rc) return throw_c1(env, rc);
+  return out;
+}
+napi_value MdctFromBands(napi_env env, napi_callback_info info) { // (ctx, Float32Array bands incl. halo, haloFrames, Int32Array modes) -> [coefs, bandsWindowed]
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  c1_ctx *ctx; void *d, *m; size_t n, nm; int32_t halo = 0;
+  if (!get_external(env, argv[0], &ctx) || !get_typed(env, argv[1], napi_float32_array, &d, &n)) return nullptr;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &halo));
+  if (!get_typed(env, argv[3], napi_int32_array, &m, &nm)) return nullptr;
+  if (n % 512 || halo < 0 || halo > 1 || (size_t)halo > n / 512 || nm != 3 * (n / 512 - (size_t)halo)) { napi_throw_type_error(env, nullptr, "mdctFromBands: whole frames and three block modes per frame"); return nullptr; }
+  const int64_t frames = (int64_t)(n / 512) - halo;
+  float *c, *bw;
+  napi_value coefs = make_f32(env, (size_t)frames * 512, &c), windowed = make_f32(env, (size_t)frames * 512, &bw), arr;
+  const int rc = c1_mdct_batch(ctx, static_cast<const float *>(d), frames, halo, static_cast<const int32_t *>(m), c, bw);
+  if (rc) return throw_c1(env, rc);
+  NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+  NAPI_OK(napi_set_element(env, arr, 0, coefs));
+  NAPI_OK(napi_set_element(env, arr, 1, windowed));
+  return arr;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
   const napi_property_descriptor props[] = {
       {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},
@@ -555,6 +647,11 @@ napi_value Init(napi_env env, napi_value exports) {
       {"encStreamPush", nullptr, EncStreamPush, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"decStreamCreate", nullptr, DecStreamCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"decStreamPush", nullptr, DecStreamPush, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"quantize", nullptr, Quantize, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"dequantize", nullptr, Dequantize, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"fft", nullptr, Fft, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"qmfAnalysis", nullptr, QmfAnalysis, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"mdctFromBands", nullptr, MdctFromBands, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;

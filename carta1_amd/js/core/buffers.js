@@ -7,5 +7,7 @@ export class BufferPool {
     this.encoderStream = null // c1_enc_stream, created by the first encode() closure call
     this.decoderStream = null // c1_dec_stream
     this.encoderOptionsKey = null
+    this.qmfHistory = null // qmfAnalysisStage on its own: the previous frame's PCM (the QMF delay lines are made of it)
+    this.mdctPreviousBands = null // mdctStage on its own: the previous frame's band samples (mdctOverlap is made of their tails)
   }
 }

@@ -65,6 +65,26 @@ async function main() {
   try { await c1.decodeAeaPcm('nope') } catch (err) { rejected = err }
   ok(rejected instanceof TypeError && rejected.message === 'ATRAC1 decoding requires AEA bytes or a Blob', 'decodeAeaPcm TypeError')
   ok(native().abiVersion() === 3, 'addon loads')
+  // every name the reference exports (codec/index.js:26-47) is exported here, with the kind of value it is there
+  {
+    const fns = ['pipe', 'encode', 'decode', 'qmfAnalysisStage', 'mdctStage', 'serializeFrame', 'deserializeFrame', 'quantize', 'dequantize',
+      'decodeAeaPcm', 'encodeAeaPcm']
+    const classes = ['AeaFile', 'BufferPool', 'EncoderOptions', 'AudioProcessor', 'FFT']
+    const tables = ['WORD_LENGTH_BITS', 'SPECS_PER_BFU', 'SCALE_FACTORS', 'BFU_START_LONG']
+    ok(fns.every((n) => typeof c1[n] === 'function') && classes.every((n) => typeof c1[n] === 'function' && c1[n].prototype) &&
+       tables.every((n) => c1[n] && c1[n].length > 0) && typeof c1.FFT.fft === 'function' && fns.length + classes.length + tables.length === 20,
+       'all twenty exports of the reference\'s codec/index.js are present')
+    // call shapes (no device needed): the stage factories take a context with a bufferPool and throw the reference's messages without one
+    let m1 = '', m2 = ''
+    try { c1.qmfAnalysisStage({}) } catch (x) { m1 = x.message }
+    try { c1.mdctStage(null) } catch (x) { m2 = x.message }
+    ok(m1 === 'qmfAnalysisStage: bufferPool is required' && m2 === 'mdctStage: bufferPool is required' &&
+       typeof c1.qmfAnalysisStage({ bufferPool: new c1.BufferPool() }) === 'function' && typeof c1.mdctStage({ bufferPool: new c1.BufferPool() }) === 'function',
+       'qmfAnalysisStage / mdctStage factories: context handling as in the reference')
+    const one = new Float32Array([3]), zero = new Float32Array([0])
+    c1.FFT.fft(one, zero)
+    ok(one[0] === 3 && zero[0] === 0, 'FFT.fft of size 1 returns at once (fft.js:16)')
+  }
 
   if (!gpu) {
     let err = null
@@ -92,6 +112,56 @@ async function main() {
       const l8 = Buffer.from(pcmOut[0].buffer, pcmOut[0].byteOffset, 8 * 512 * 4)
       const r8 = Buffer.from(pcmOut[1].buffer, pcmOut[1].byteOffset, 8 * 512 * 4)
       ok(pcmOut.length === 2 && pcmOut[0].length === n && l8.equals(head.subarray(0, 16384)) && r8.equals(head.subarray(16384)), `decodeAeaPcm ${name}: PCM == reference`)
+    }
+    // the single-stage exports against the reference's own outputs (tests/golden/quantize.json, stage_exports.json)
+    {
+      const be32 = (h) => Buffer.from(h, 'hex').readFloatBE(0)
+      const qv = JSON.parse(fs.readFileSync(path.join(G, 'quantize.json')))
+      let okQ = true, okD = true
+      for (const v of qv) {
+        const x = Float32Array.from(v.x.map(be32))
+        const q = c1.quantize(x, v.sfi, v.bits)
+        if (!(q instanceof Int32Array) || Array.from(q).join() !== v.q.join()) okQ = false
+        const d = c1.dequantize(Int32Array.from(v.q), v.sfi, v.bits)
+        if (!(d instanceof Float32Array) || !v.d.every((h, i) => Object.is(be32(h), d[i]))) okD = false
+      }
+      ok(okQ, `quantize == reference on ${qv.length} vectors (incl. the | 0 wrap)`)
+      ok(okD, 'dequantize == reference on the same vectors')
+      const sx = JSON.parse(fs.readFileSync(path.join(G, 'stage_exports.json')))
+      const wh = (seed, n, amp) => { const r = xorshift(seed); const x = new Float32Array(n); for (let i = 0; i < n; i++) x[i] = Math.fround(r() * amp); return x }
+      let okE = true
+      for (const v of sx.quantize) {
+        const q = c1.quantize(wh(v.seed, v.n, v.amp), v.sfi, v.bits)
+        if (Array.from(q).join() !== v.q.join() || hex(c1.dequantize(q, v.sfi, v.bits)) !== v.d) okE = false
+      }
+      ok(okE, 'quantize / dequantize at 2, 3, 12 and 16 bits, bits 0 and scale factor 0 == reference')
+      let okF = true
+      for (const v of sx.fft) {
+        const re = wh(v.seed_real, v.n, v.amp), im = wh(v.seed_imag, v.n, v.amp)
+        c1.FFT.fft(re, im)
+        if (hex(re) !== v.real || hex(im) !== v.imag) okF = false
+      }
+      ok(okF, 'FFT.fft in place, sizes 2..1024 == reference bit for bit')
+      let okB = true, okC = true, okW = true
+      for (const run of sx.stages) {
+        const pool = new c1.BufferPool()
+        const qmf = c1.qmfAnalysisStage({ bufferPool: pool }), mdct = c1.mdctStage({ bufferPool: pool })
+        const pcm = wh(run.seed, 4 * 512, 0.5)
+        for (let fi = 0; fi < 4; fi++) {
+          const a = qmf(pcm.subarray(fi * 512, (fi + 1) * 512).slice())
+          if (a.bands.length !== 3 || !a.bands.every((b, i) => hex(b) === run.frames[fi].bands_raw[i])) okB = false
+          const r = mdct({ bands: a.bands, blockModes: run.modes, originalFrame: 'tag' })
+          if (hex(r.coefficients) !== run.frames[fi].coefficients || r.coefficients.length !== 512) okC = false
+          if (r.bands !== a.bands || r.originalFrame !== 'tag' || !r.bands.every((b, i) => hex(b) === run.frames[fi].bands_after[i])) okW = false
+        }
+      }
+      ok(okB, 'qmfAnalysisStage over 4 consecutive frames == reference bands')
+      ok(okC, 'mdctStage, block modes [0,0,0] [2,2,3] [0,2,0] [2,0,3] == reference coefficients')
+      ok(okW, 'mdctStage hands on the same band arrays, windowed in place as the reference leaves them')
+      // pipe() of the two stages, as an application would compose them
+      const p = c1.pipe({ bufferPool: new c1.BufferPool() }, c1.qmfAnalysisStage, () => (x) => Object.assign(x, { blockModes: [0, 0, 0] }), c1.mdctStage)
+      const r0 = p(wh(51, 512, 0.5))
+      ok(hex(r0.coefficients) === sx.stages[0].frames[0].coefficients, 'pipe(qmfAnalysisStage, ..., mdctStage) == reference')
     }
     // frame closures continue a stream; decode() closure on frame fields
     const x = pinkT(3, 8 * 512)

@@ -230,6 +230,29 @@ int c1_decode_wav16_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64
  * already the AEA body: header + units is the whole file).  title is UTF-8, truncated to 255 bytes. */
 int c1_aea_header(const char *title, uint32_t unit_count, int channels, uint8_t out[2048]);
 
+/* ---- the single-stage functions the reference exports next to encode()/decode() (codec/index.js:30-35,42).  Host
+ *      pointers, synchronous; the arithmetic runs on the device in the reference's own number model.  They serve
+ *      applications that import these names; the hot path itself never calls them (it quantizes inside the packing kernel
+ *      and transforms inside the analysis kernels). ------------------------------------------------------------------- */
+/* quantize, codec/coding/quantization.js:34-56: out[i] = clamp(((x norm) +- 0.5) | 0), norm = ((1 << (bits - 1)) - 1) /
+ * SCALE_FACTORS[sfi]; zeros when bits or sfi is 0 */
+int c1_quantize(c1_ctx *ctx, const float *coefficients, int n, int scale_factor_index, int bits_per_sample, int32_t *out);
+/* dequantize, quantization.js:65-78: Float32((q SCALE_FACTORS[sfi]) / ((1 << (bits - 1)) - 1)) */
+int c1_dequantize(c1_ctx *ctx, const int32_t *quantized, int n, int scale_factor_index, int bits_per_sample, float *out);
+/* FFT.fft, codec/transforms/fft.js:14-68: in place on real[n], imag[n], n a power of two; w = (cos, sin)(-2 pi / stride) for
+ * stride = 2, 4, .., n as the HOST's Math.cos / Math.sin give them (log2(n) pairs; the reference computes them per call, :37-39) */
+int c1_fft(c1_ctx *ctx, float *real, float *imag, int n, const double *w);
+/* qmfAnalysisStage, codec/pipeline/encoder.js:57-96, for `frames` consecutive frames of one channel: pcm = (halo_frames + frames)
+ * * 512 samples, the first halo_frames (0..2) being the stream's history (zero history = a fresh BufferPool); bands =
+ * frames * 512 floats, low128 | mid128 | high256 (the high band behind its 39-sample delay) per frame */
+int c1_qmf_analysis_batch(c1_ctx *ctx, const float *pcm, int64_t frames, int halo_frames, float *bands);
+/* mdctStage, encoder.js:170-349, from band samples: bands = (halo_frames + frames) * 512 floats as above, the first frame (when
+ * halo_frames = 1) being the previous frame of the stream, whose band tails make mdctOverlap (:309-316; none: a fresh pool's zero
+ * overlap); block_modes = frames * 3 (0 long, else short); coefs = frames * 512 (as quantizationStage receives them);
+ * bands_windowed (optional) = frames * 512: the band arrays as the reference leaves them, windowed in place (:244,292,314) */
+int c1_mdct_batch(c1_ctx *ctx, const float *bands, int64_t frames, int halo_frames, const int32_t *block_modes, float *coefs,
+                  float *bands_windowed);
+
 /* ---- stage taps for bring-up and stage-level parity tests (device pointers) ---------------- */
 /* bands: frames*channels*512 floats (low128|mid128|high256 per unit index, before windowing);
  * coefs: same shape (MDCT coefficients as quantizationStage receives them);
