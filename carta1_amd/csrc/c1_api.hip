@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -42,6 +43,7 @@ int fail(int code, const char *fmt, ...) {
 
 std::mutex g_tables_mutex;
 bool g_tables_custom = false;
+std::atomic<uint64_t> g_tables_gen{0};        // bumped by every c1_set_tables(): pooled contexts made before it are retired
 c1_tables g_tables;
 
 void default_tables(c1_tables *t) {
@@ -889,12 +891,13 @@ int c1_get_default_tables(c1_tables *out) {
 
 int c1_set_tables(const c1_tables *tables) {
   std::lock_guard<std::mutex> lock(g_tables_mutex);
-  if (!tables) { g_tables_custom = false; return C1_OK; }
+  if (!tables) { g_tables_custom = false; g_tables_gen++; return C1_OK; }
   const double *p = reinterpret_cast<const double *>(tables);
   for (size_t i = 0; i < sizeof(c1_tables) / sizeof(double); i++)
     if (!std::isfinite(p[i])) return fail(C1_ERR_ARG, "table entry %zu is not finite", i);
   g_tables = *tables;
   g_tables_custom = true;
+  g_tables_gen++;
   return C1_OK;
 }
 
@@ -1748,24 +1751,70 @@ int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fra
 
 // ---- one batch over several devices ------------------------------------------------------------------------------------
 namespace {
+// Contexts for the *_multi entry points: one per shard for the duration of a call, checked out of a process-wide pool and
+// given back at its end.  A context is never shared between two calls in flight nor destroyed while one uses it (a second
+// call that needs the same device meanwhile gets another context); a context made before the last c1_set_tables() is
+// retired when it comes back, so the *_multi entry points follow the installed tables like a context created afresh.
 struct ShardPool {
+  struct Entry { int device; uint64_t tables_gen; c1_ctx *ctx; bool busy; };
   std::mutex mu;
-  std::vector<std::pair<int, c1_ctx *>> ctxs;      // entry i serves shard i when its device matches
-  c1_ctx *get(size_t shard, int device, int *rc) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (ctxs.size() <= shard) ctxs.resize(shard + 1, {-1, nullptr});
-    if (ctxs[shard].second && ctxs[shard].first != device) { c1_ctx_destroy(ctxs[shard].second); ctxs[shard] = {-1, nullptr}; }
-    if (!ctxs[shard].second) {
-      c1_ctx *c = nullptr;
-      *rc = c1_ctx_create(device, nullptr, &c);
-      if (*rc) return nullptr;
-      ctxs[shard] = {device, c};
+  std::vector<Entry> entries;
+  c1_ctx *checkout(int device, int *rc) {
+    const uint64_t gen = g_tables_gen.load();
+    std::vector<c1_ctx *> stale;
+    c1_ctx *found = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (size_t i = 0; i < entries.size();) {
+        Entry &e = entries[i];
+        if (!e.busy && e.tables_gen != gen) { stale.push_back(e.ctx); entries.erase(entries.begin() + (long)i); continue; }
+        if (!found && !e.busy && e.device == device) { e.busy = true; found = e.ctx; }
+        ++i;
+      }
     }
+    for (c1_ctx *c : stale) c1_ctx_destroy(c);
     *rc = C1_OK;
-    return ctxs[shard].second;
+    if (found) return found;
+    c1_ctx *c = nullptr;
+    *rc = c1_ctx_create(device, nullptr, &c);
+    if (*rc) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    entries.push_back({device, gen, c, true});
+    return c;
+  }
+  void give_back(c1_ctx *c) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry &e : entries) if (e.ctx == c) e.busy = false;
   }
 };
 ShardPool g_shards;
+struct ShardLease {           // the contexts of one *_multi call
+  std::vector<c1_ctx *> ctxs;
+  ~ShardLease() { for (c1_ctx *c : ctxs) if (c) g_shards.give_back(c); }
+  int take(const int *devices, int shards) {
+    for (int s = 0; s < shards; s++) {
+      int rc = C1_OK;
+      c1_ctx *c = g_shards.checkout(devices[s], &rc);
+      if (rc) return rc;                               // c1_last_error() of this thread holds the reason
+      ctxs.push_back(c);
+    }
+    return C1_OK;
+  }
+};
+
+// Host memory of the caller pinned in place for the duration of a call (hipHostRegister), so that every shard streams its
+// range at the page-locked PCIe rate without the caller having allocated through c1_host_alloc.  Memory that is page-locked
+// already, or that the runtime declines to register, is left as it is (the shards then copy, compute, copy).
+struct ScopedHostPin {
+  std::vector<void *> pinned;
+  void pin(const void *p, size_t bytes) {
+    static const bool off = getenv("C1_NO_HOST_REGISTER") != nullptr;
+    if (off || !p || bytes < ((size_t)1 << 20) || is_pinned_host(p)) return;
+    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) pinned.push_back(const_cast<void *>(p));
+    else (void)hipGetLastError();
+  }
+  ~ScopedHostPin() { for (void *p : pinned) (void)hipHostUnregister(p); }
+};
 
 // contiguous ranges whose sizes differ by at most one frame
 void shard_plan(int64_t frames, int shards, std::vector<std::pair<int64_t, int64_t>> *plan) {
@@ -1791,10 +1840,15 @@ int c1_encode_batch_multi(const int *devices, int n_devices, const float *const 
   const int shards = (int)std::min<int64_t>(n_devices, frames);
   std::vector<std::pair<int64_t, int64_t>> plan;
   shard_plan(frames, shards, &plan);
-  std::vector<c1_ctx *> ctxs(shards);
-  for (int s = 0; s < shards; s++) {
-    ctxs[s] = g_shards.get((size_t)s, devices[s], &rc);
-    if (rc) return rc;                               // c1_last_error() of this thread holds the reason
+  ShardLease lease;
+  if ((rc = lease.take(devices, shards))) return rc;
+  const std::vector<c1_ctx *> &ctxs = lease.ctxs;
+  // One registration per buffer, made here before the shards start and dropped after they have all finished: the shards'
+  // ranges (and their halos) overlap at page granularity, so they cannot pin their own parts independently.
+  ScopedHostPin pin;
+  if (hipSetDevice(ctxs[0]->device) == hipSuccess) {
+    for (int c = 0; c < channels; c++) pin.pin(pcm[c] - (size_t)halo_frames * 512, (size_t)(frames + halo_frames) * 512 * sizeof(float));
+    pin.pin(units, (size_t)frames * channels * C1_UNIT_BYTES);
   }
   std::vector<int> rcs(shards, C1_OK);
   std::vector<std::string> errs(shards);
@@ -1826,10 +1880,13 @@ int c1_decode_batch_multi(const int *devices, int n_devices, const uint8_t *unit
   const int shards = (int)std::min<int64_t>(n_devices, frames);
   std::vector<std::pair<int64_t, int64_t>> plan;
   shard_plan(frames, shards, &plan);
-  std::vector<c1_ctx *> ctxs(shards);
-  for (int s = 0; s < shards; s++) {
-    ctxs[s] = g_shards.get((size_t)s, devices[s], &rc);
-    if (rc) return rc;
+  ShardLease lease;
+  if ((rc = lease.take(devices, shards))) return rc;
+  const std::vector<c1_ctx *> &ctxs = lease.ctxs;
+  ScopedHostPin pin;
+  if (hipSetDevice(ctxs[0]->device) == hipSuccess) {
+    pin.pin(units - (size_t)halo_units * channels * C1_UNIT_BYTES, (size_t)(frames + halo_units) * channels * C1_UNIT_BYTES);
+    for (int c = 0; c < channels; c++) pin.pin(pcm[c], (size_t)frames * 512 * sizeof(float));
   }
   std::vector<int> rcs(shards, C1_OK);
   std::vector<std::string> errs(shards);

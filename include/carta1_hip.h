@@ -160,7 +160,9 @@ int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t 
  * dependency between frames beyond a bounded PCM history): contiguous frame ranges, one per entry of `devices`, each
  * encoded by its own host thread on a context of that device from its 2 frames of real PCM history; no collective, the
  * ranges land in `units` by frame index.  A device may be listed more than once (each entry gets its own context).
- * Contexts are created on first use and kept for the life of the process.  Bit-identical to c1_encode_batch. */
+ * Contexts come from a process-wide pool: created on first use, leased to one call at a time (concurrent calls get their
+ * own), made anew after c1_set_tables().  Host buffers that are not page-locked already are pinned in place for the
+ * duration of the call, so that every shard streams its range.  Bit-identical to c1_encode_batch on a fresh context. */
 int c1_encode_batch_multi(const int *devices, int n_devices, const float *const *pcm, int channels, int64_t frames,
                           int halo_frames, const c1_encode_options *opts, uint8_t *units);
 /* decode twin: every range starts from the unit(s) of the frame before it */

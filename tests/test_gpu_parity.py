@@ -613,3 +613,45 @@ def test_multi_device_entry_points_equal_one_device(ctx):
             assert np.array_equal(a[c].view(np.uint32), b[c].view(np.uint32))
     mono = c1.encode_multi([chans[0][:5 * 512]], c1.EncoderOptions(), devices=(0, 0, 0, 0, 0, 0, 0, 0))   # more shards than frames
     assert np.array_equal(mono, ctx.encode([chans[0][:5 * 512]], c1.EncoderOptions()))
+
+
+def test_multi_entry_points_follow_the_installed_tables_and_survive_concurrent_calls(ctx):
+    """the pooled contexts of the *_multi entry points are leased per call and retired when the tables change: after
+    c1_set_tables(custom) encode_multi equals a context created afresh (not the context the pool made under the default
+    tables), back again after c1_set_tables(NULL); and two threads sharing devices in opposite order get their own
+    results (each call holds its contexts until it returns)"""
+    import ctypes as C
+    import threading
+    import carta1_amd as c1
+    from carta1_amd import capi
+    n = 600 * 512
+    chans = [O.gen_pinkT(13, n), O.gen_white(14, n)]
+    opts = c1.EncoderOptions({'fixedBlockModes': [0, 0, 0]})
+    base = c1.encode_multi(chans, opts, devices=(0, 0))
+    assert np.array_equal(base, ctx.encode(chans, opts))
+    t = capi.default_tables()
+    t.window_short[7] *= 1.01                       # any table that changes the output will do
+    try:
+        capi.check(capi.load().c1_set_tables(C.byref(t)))
+        fresh = c1.Context(0)
+        want = fresh.encode(chans, opts).copy()
+        fresh.close()
+        assert not np.array_equal(want, base)
+        assert np.array_equal(c1.encode_multi(chans, opts, devices=(0, 0)), want)
+    finally:
+        capi.check(capi.load().c1_set_tables(None))
+    assert np.array_equal(c1.encode_multi(chans, opts, devices=(0, 0)), base)
+    # concurrent calls
+    other = [O.gen_white(15, n), O.gen_pinkT(16, n)]
+    want_b = ctx.encode(other, c1.EncoderOptions()).copy()
+    out = {}
+
+    def run(name, ch, o, dev):
+        for _ in range(3):
+            out[name] = c1.encode_multi(ch, o, devices=dev)
+    th = [threading.Thread(target=run, args=('a', chans, opts, (0, 0, 0))), threading.Thread(target=run, args=('b', other, c1.EncoderOptions(), (0, 0)))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert np.array_equal(out['a'], base) and np.array_equal(out['b'], want_b)

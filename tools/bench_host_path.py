@@ -13,6 +13,19 @@ for rep in range(2):
     t0 = time.perf_counter(); p = ctx.decode(u, 2); t1 = time.perf_counter()
     print('decode_batch: %.1f ms -> %.2f M frames/s' % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e6))
 
+# the multi-device entry point from the same pageable arrays: it pins the caller's memory in place for the call (hipHostRegister),
+# so each shard streams at the page-locked rate; C1_NO_HOST_REGISTER=1 shows the rate without that
+import os
+for dev in ((0,), (0, 0)):
+    for rep in range(3):
+        t0 = time.perf_counter(); um = c1.encode_multi(chs, opt, devices=dev); t1 = time.perf_counter()
+        print('encode_batch_multi%s from pageable arrays%s: %.1f ms -> %.2f M frames/s (%.1f GB/s of PCM)' % (
+            list(dev), ' (no host register)' if os.environ.get('C1_NO_HOST_REGISTER') else '', (t1 - t0) * 1e3, n / (t1 - t0) / 1e6, n * 4096 / (t1 - t0) / 1e9))
+    assert np.array_equal(um, u)
+for rep in range(2):
+    t0 = time.perf_counter(); pm = c1.decode_multi(u, 2, devices=(0, 0)); t1 = time.perf_counter()
+    print('decode_batch_multi[0, 0] from pageable arrays: %.1f ms -> %.2f M frames/s' % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e6))
+
 # the same batch from page-locked arrays: streamed in chunks (upload | kernels | download overlap)
 pch = [c1.pinned_empty(n * 512, np.float32) for _ in range(2)]
 for a, b in zip(pch, chs):
