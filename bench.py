@@ -109,7 +109,8 @@ def cpu_baseline(modes, bias, frames_one, frames_each):
     with concurrent.futures.ThreadPoolExecutor(cores) as ex:      # ctypes calls release the GIL
         list(ex.map(shard, range(cores)))
     dt = time.perf_counter() - t0
-    return {'value': total / dt, 'unit': 'stereo frames/s', 'cores': cores, 'kind': 'port',
+    node_js = node_baseline(frames_one // 4, cores)
+    return {'value': total / dt, 'unit': 'stereo frames/s', 'cores': cores, 'kind': 'port', 'node_js': node_js,
             'one_thread': one,
             'sample': '%d stereo frames of the same white-noise workload on %d threads (%.1f s), and %d frames on one '
                       'thread; C restatement of the reference, encode incl. unit packing' % (total, cores, dt, frames_one),
@@ -153,6 +154,25 @@ def valu_roofline(kind, launch_ms, units_per_launch, section):
         out['clock_ghz_from_counters'] = clock_ghz
         out['frac_this_run'] = out['achieved'] / out['peak']
     return out
+
+
+def node_baseline(frames, threads):
+    """the encode path restated in JavaScript (oracle/js/atrac1_oracle.mjs), run by this host's
+    Node on one thread and on worker_threads x cores; the script first checks itself against the reference's golden vectors
+    and times nothing if they do not reproduce byte for byte."""
+    import shutil
+    node = shutil.which('node')
+    if not node:
+        return {'error': 'node is not installed on this host'}
+    try:
+        r = subprocess.run([node, os.path.join(ROOT, 'oracle', 'js', 'cpu_baseline.mjs'), '--frames', str(max(1024, frames)), '--threads', str(threads)],
+                           capture_output=True, text=True, timeout=300)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out['sample'] = ('%d stereo frames of the same white-noise workload on one thread, %d per thread on %d worker_threads; JavaScript restatement of '
+                         'the reference under this host\'s Node, parity-checked against tests/golden first' % (out.get('one_thread_frames', 0), out.get('frames_per_thread', 0), threads))
+        return out
+    except Exception as e:   # noqa: BLE001
+        return {'error': str(e)[:300]}
 
 
 def self_launch(args):
