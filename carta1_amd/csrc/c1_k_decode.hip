@@ -45,7 +45,8 @@ struct alignas(16) DecodeLds {
   uint32_t desc[52];    // per BFU: bits(5) | sfi(6) << 5 | mantissa bit offset << 11 (may exceed the unit for arbitrary bytes)
   R sf_tab[64];         // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
   R inv_tab[16];        // coefficient would cost a cache round trip each)
-  R step[52];           // per BFU of the unit: SF * RN(1 / range) (binary64 decoder with dq_step)
+  R step[52];           // per BFU of the unit: SF * RN(1 / range), 0 for a silent BFU (dq_step; the binary32 decoder always)
+  int16_t dshort[52];   // BFU_START_SHORT[b] - (first slot of b): where a short band's coefficients go, relative to slot order
   union alignas(16) {
     float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
     float band[512];    // reconstructed bands: born at the overlap-add
@@ -233,13 +234,23 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
   S.sf_tab[lane] = (real)C1_TABLES(L.tables)->scale_factors[lane];
   if (lane < 16) S.inv_tab[lane] = (real)C1_TABLES(L.tables)->inv_range[lane];
   // lane-only geometry, computed once per wave
-  uint32_t slot[8];                                  // BFU(6) | index inside the BFU(5) << 6 | short-block position(9) << 11
+  // A lane dequantizes the eight CONSECUTIVE slots 8 lane .. 8 lane + 7 (BFU-major order = bit-stream order = coefficient
+  // order of a long band): one running bit cursor, one 64-bit window read per mantissa, two 16-byte stores.  They lie in at
+  // most three BFUs b0, b0 + 1, b0 + 2: dq_geo = b0 | index of slot 8 lane inside b0 << 6 | mask of the slots past the first
+  // boundary << 11 | mask of the slots past the second << 19.
+  uint32_t dq_geo;
+  {
+    const int s0 = 8 * lane0, b0 = bfu_of_slot(s0);
+    uint32_t m1 = 0, m2 = 0;
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int p = lane0 + 64 * m;                    // coefficient slot in BFU-major order (== long-block position)
-    const int b = bfu_of_slot(p), j = p - kBfuFirst[b];
-    slot[m] = (uint32_t)b | ((uint32_t)j << 6) | ((uint32_t)(kStartShort[b] + j) << 11);
+    for (int m = 0; m < 8; m++) {
+      const int k = bfu_of_slot(s0 + m) - b0;
+      m1 |= (k >= 1 ? 1u : 0u) << m;
+      m2 |= (k >= 2 ? 1u : 0u) << m;
+    }
+    dq_geo = (uint32_t)b0 | ((uint32_t)(s0 - kBfuFirst[b0]) << 6) | (m1 << 11) | (m2 << 19);
   }
+  if (lane0 < 52) S.dshort[lane0] = (int16_t)((int)kStartShort[lane0] - (int)kBfuFirst[lane0]);
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
   const IMixGeometry IGL = imix_geometry<R>(lane0, FrameModes{0, 0, 0});   // all-long frames
   const TablesRsrc RT = tables_rsrc(L.tables);
@@ -255,11 +266,6 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
 
     // ---------------- deserializeFrame (serialization.js:111-176) ----------------
     if (lane < 53) S.words[lane] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane]);
-    {
-      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      reinterpret_cast<float4 *>(S.cb.coef)[lane] = zero4;
-      reinterpret_cast<float4 *>(S.cb.coef)[64 + lane] = zero4;
-    }
     __syncthreads();
     const uint32_t header = S.words[0] >> 16;
     const int m0 = 2 - (int)((header >> 14) & 3), m1 = 2 - (int)((header >> 12) & 3), m2 = 3 - (int)((header >> 10) & 3);
@@ -273,40 +279,75 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
     const int scan = wave_inclusive_scan(mybits);
     if (lane < 52) {
       S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
-      if constexpr (!F32) S.step[lane] = S.sf_tab[sfi] * S.inv_tab[wl_bits(wl) > 0 ? wl_bits(wl) - 1 : 0];   // SF * RN(1 / range): see dq_step
+      // SF * RN(1 / range) (see dq_step); a BFU with scale factor 0 dequantizes to zeros (quantization.js:66-68)
+      S.step[lane] = sfi != 0 ? S.sf_tab[sfi] * S.inv_tab[wl_bits(wl) > 0 ? wl_bits(wl) - 1 : 0] : (real)0;
     }
     __syncthreads();
     // ---------------- dequantizationStage (decoder.js:52-98) ----------------
     const bool all_long = (m0 | m1 | m2) == 0;
+    {
+      const int b0 = (int)(dq_geo & 63u), b1 = b0 + 1 < 52 ? b0 + 1 : 51, b2 = b0 + 2 < 52 ? b0 + 2 : 51;
+      const uint32_t in1 = (dq_geo >> 11) & 255u, in2 = (dq_geo >> 19) & 255u;
+      const uint32_t d0 = S.desc[b0], d1 = S.desc[b1], d2 = S.desc[b2];
+      const real st0 = S.step[b0], st1 = S.step[b1], st2 = S.step[b2];
+      const int nb0 = (int)(d0 & 31u), nb1 = (int)(d1 & 31u), nb2 = (int)(d2 & 31u);
+      // the slow formulations are only needed where the tables fail the host's check (binary64) or the unit's mantissas run
+      // past its 212 bytes (bytes no encoder wrote: unpackBits then returns what is left, bitstream.js:49-70)
+      const int last_bits = (int)(S.desc[51] >> 11) + (int)(S.desc[51] & 31u) * 20;
+      const bool plain = last_bits <= C1_UNIT_BYTES * 8 && (F32 || T->dq_step != 0);
+      int pos = (int)(d0 >> 11) + (int)((dq_geo >> 6) & 31u) * nb0;      // bit position of the lane's first mantissa
+      float v[8];
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int sb = slot[m] & 63, sj = (slot[m] >> 6) & 31;
-      const uint32_t dsc = S.desc[sb];
-      const int bits = dsc & 31;
-      if (bits == 0) continue;                                  // BFU not coded (or beyond nBfu: its word length reads 0)
-      const int sf = (dsc >> 5) & 63;
-      const uint32_t raw = get_bits_be(S.words, (int)(dsc >> 11) + sj * bits, bits);
-      const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;     // bitstream.js:78-82
-      const int32_t range = (1 << (bits - 1)) - 1;
-      float v = 0.0f;                                                                               // quantization.js:65-78
-      if (sf != 0) {
-        if constexpr (F32) v = ((float)q * S.sf_tab[sf]) * S.inv_tab[bits - 1];
-        else {
-        if (T->dq_step) {
-          v = f32((double)q * S.step[sb]);                      // == Float32((q * SF) / range) for every input (checked on the host)
+      for (int m = 0; m < 8; m++) {
+        const bool p1 = (in1 >> m) & 1u, p2 = (in2 >> m) & 1u;
+        const int bits = p2 ? nb2 : (p1 ? nb1 : nb0);
+        const real st = p2 ? st2 : (p1 ? st1 : st0);
+        if (plain) {
+          const int w = pos >> 5, o = pos & 31;
+          const uint64_t two = ((uint64_t)S.words[w] << 32) | (uint64_t)S.words[w + 1];
+          // the mantissa as a signed bit field: bits o .. o + bits of the 64-bit window (bitstream.js:78-82)
+          const int64_t field = (int64_t)(two << o) >> ((64 - bits) & 63);
+          const int32_t q = bits != 0 ? (int32_t)field : 0;
+          v[m] = (float)((real)q * st);                           // == Float32((q * SF) / range) for every input (checked on the host)
         } else {
-        const double a = (double)q * S.sf_tab[sf];
-        if (T->dq_fast) {
-          const double y = S.inv_tab[bits - 1], q0 = a * y;
-          v = f32(__builtin_fma(__builtin_fma(-q0, (double)range, a), y, q0));                  // == a / range (checked on the host)
-        } else {
-          v = f32(a / (double)range);
+          const uint32_t dsc = p2 ? d2 : (p1 ? d1 : d0);
+          const int sf = (int)((dsc >> 5) & 63u);
+          float r = 0.0f;
+          if (bits != 0) {
+            const uint32_t raw = get_bits_be(S.words, pos, bits);
+            const int32_t q = raw >= (1u << (bits - 1)) ? (int32_t)raw - (1 << bits) : (int32_t)raw;
+            const int32_t range = (1 << (bits - 1)) - 1;
+            if (sf != 0) {                                          // quantization.js:65-78
+              if constexpr (F32) r = (float)q * (float)st;
+              else {
+                const double a = (double)q * S.sf_tab[sf];
+                if (T->dq_step) r = f32((double)q * (double)st);
+                else if (T->dq_fast) {
+                  const double y = S.inv_tab[bits - 1], q0 = a * y;
+                  r = f32(__builtin_fma(__builtin_fma(-q0, (double)range, a), y, q0));              // == a / range (checked on the host)
+                } else r = f32(a / (double)range);
+              }
+            }
+          }
+          v[m] = r;
         }
-        }
+        pos += bits;
+      }
+      if (all_long) {
+        float4 *dst = reinterpret_cast<float4 *>(S.cb.coef + 8 * lane);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        // a short band's BFUs are interleaved over its blocks (BFU_START_SHORT, constants.js:46-52)
+        const int e0 = (b0 >= 36 ? m2 : (b0 >= 20 ? m1 : m0)) != 0 ? (int)S.dshort[b0] : 0;
+        const int e1 = (b1 >= 36 ? m2 : (b1 >= 20 ? m1 : m0)) != 0 ? (int)S.dshort[b1] : 0;
+        const int e2 = (b2 >= 36 ? m2 : (b2 >= 20 ? m1 : m0)) != 0 ? (int)S.dshort[b2] : 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const bool p1 = (in1 >> m) & 1u, p2 = (in2 >> m) & 1u;
+          S.cb.coef[8 * lane + m + (p2 ? e2 : (p1 ? e1 : e0))] = v[m];
         }
       }
-      const int mode = sb >= 36 ? m2 : (sb >= 20 ? m1 : m0);
-      S.cb.coef[mode == 0 ? lane + 64 * m : (int)(slot[m] >> 11)] = v;
     }
     __syncthreads();
 
