@@ -52,7 +52,9 @@ struct alignas(16) DecodeLds {
     float band[512];    // reconstructed bands: born at the overlap-add
   } cb;
   union alignas(16) {
-    struct { union alignas(16) { float2 z[320]; } zz; alignas(16) float mid[512]; } m;   // IMDCT: points (4 pad per 16), outputs
+    // IMDCT: points (4 pad per 16), then the outputs in the same memory: the post-twiddle writes `mid` from registers after the
+    // last round has read its points (one wave: LDS operations execute in issue order)
+    struct { union alignas(16) { float2 z[320]; float mid[512]; } zz; } m;
     struct { alignas(16) R w2[454]; } q2;                        // stage-2 synthesis work buffer (padded 2 per 4)
     struct { alignas(16) R w1[698]; } q1;                        // stage-1 synthesis work buffer (padded 2 per 8), after w2 is consumed
   } u;
@@ -157,6 +159,9 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
   constexpr bool F32 = std::is_same<real, float>::value;
   constexpr int kPair = F32 ? 8 : 16;
   float2 x[4];
+  // Lane-varying table values are cache round trips: every round asks for the values of the NEXT round before it starts
+  // computing (as the encoder's cores do), so the loads are in flight during the arithmetic and the LDS exchange
+  const pair bwa = table_pair_r<real>(R, G.twb), bwb = table_pair_r<real>(R, G.twb + 4 * kPair), bwc = table_pair_r<real>(R, G.twb + 8 * kPair);
   {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -177,38 +182,46 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
     dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
     dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
   }
+  // round C's twiddles (long bands), or the post-twiddle pairs of a frame that ends after round B
+  pair n0, n1, n2, n3;
+  if (any_long) { n0 = table_pair_r<real>(R, G.twc); n1 = table_pair_r<real>(R, G.twc + 16 * kPair); n2 = table_pair_r<real>(R, G.twc + 32 * kPair); n3 = n0; }
+  else { n0 = table_pair_r<real>(R, G.post_tab[0]); n1 = table_pair_r<real>(R, G.post_tab[1]); n2 = table_pair_r<real>(R, G.post_tab[2]); n3 = table_pair_r<real>(R, G.post_tab[3]); }
   __syncthreads();
   {
     float2 *p = z + G.zb;
-    const pair wa = table_pair_r<real>(R, G.twb), wb = table_pair_r<real>(R, G.twb + 4 * kPair), wc = table_pair_r<real>(R, G.twb + 8 * kPair);
     x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
-    r2_bf<real>(x[0], x[1], wa); r2_bf<real>(x[2], x[3], wa);
-    r2_bf<real>(x[0], x[2], wb); r2_bf<real>(x[1], x[3], wc);
+    r2_bf<real>(x[0], x[1], bwa); r2_bf<real>(x[2], x[3], bwa);
+    r2_bf<real>(x[0], x[2], bwb); r2_bf<real>(x[1], x[3], bwc);
     if (G.is_long) { p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3]; }
   }
+  pair t0, t1, t2, t3;                                       // the post-twiddle pairs
   if (any_long) {
+    // round D's twiddles (band 2), in flight during round C
+    pair dwa, dwb;
+    if (band2_long) { dwa = table_pair_r<real>(R, G.twd); dwb = table_pair_r<real>(R, G.twd + 32 * kPair); }
     __syncthreads();
     if (G.is_long) {
       float2 *p = z + G.zc;
-      const pair wa = table_pair_r<real>(R, G.twc), wb = table_pair_r<real>(R, G.twc + 16 * kPair), wc = table_pair_r<real>(R, G.twc + 32 * kPair);
       x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
-      r2_bf<real>(x[0], x[1], wa); r2_bf<real>(x[2], x[3], wa);
-      r2_bf<real>(x[0], x[2], wb); r2_bf<real>(x[1], x[3], wc);
+      r2_bf<real>(x[0], x[1], n0); r2_bf<real>(x[2], x[3], n0);
+      r2_bf<real>(x[0], x[2], n1); r2_bf<real>(x[1], x[3], n2);
       if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
     }
+    t0 = table_pair_r<real>(R, G.post_tab[0]); t1 = table_pair_r<real>(R, G.post_tab[1]);
+    t2 = table_pair_r<real>(R, G.post_tab[2]); t3 = table_pair_r<real>(R, G.post_tab[3]);
     if (band2_long) {
       __syncthreads();
       if (G.band2) {
         const float2 *p = z + G.zd;
-        const pair wa = table_pair_r<real>(R, G.twd), wb = table_pair_r<real>(R, G.twd + 32 * kPair);
         x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
-        r2_bf<real>(x[0], x[1], wa); r2_bf<real>(x[2], x[3], wb);
+        r2_bf<real>(x[0], x[1], dwa); r2_bf<real>(x[2], x[3], dwb);
       }
     }
-  }
+  } else { t0 = n0; t1 = n1; t2 = n2; t3 = n3; }
+  __syncthreads();                                          // `mid` is the memory of `z`: every point has been read by now
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const pair t = table_pair_r<real>(R, G.post_tab[j]);
+    const pair t = j == 0 ? t0 : (j == 1 ? t1 : (j == 2 ? t2 : t3));
     const real rr = x[j].x, ii = x[j].y;
     mid[G.ox[j]] = (float)(rr * t.x + ii * t.y);            // mdct.js:177-208
     mid[G.oy[j]] = (float)(rr * t.y - ii * t.x);
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
     __syncthreads();
 
     // ---------------- imdctStage (decoder.js:116-330) ----------------
-    float *mid = S.u.m.mid;
+    float *mid = S.u.m.zz.mid;
     if (all_long) {
       imdct_r4<R>(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT);
       __syncthreads();
