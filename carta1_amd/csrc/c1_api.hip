@@ -246,51 +246,11 @@ void build_device_tables(const c1_tables &t, C1DevTables *d) {
 }
 
 // rank table of the Float32 heap priorities (bitallocation.js:226-231, 267-269)
-int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d);
-// The rank tables depend on the biased scale factors only, and the search for an integer form costs ~30 M host
-// operations when there is none: keep the last few results.
-int build_encode_opts(const c1_encode_options &o, C1DevEncOpts *d) {
-  struct Entry { double biased[64]; C1DevEncOpts opts; };
-  static std::mutex mu;
-  static std::vector<Entry> cache;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    for (const Entry &e : cache)
-      if (memcmp(e.biased, o.biased_scale_factors, sizeof e.biased) == 0) {
-        C1DevEncOpts probe;                          // the validation of the other fields, without the rank search
-        *d = e.opts;
-        if (std::isnan(o.transient_threshold)) return fail(C1_ERR_ARG, "transient_threshold is NaN");
-        d->threshold = o.transient_threshold;
-        const bool detect = o.fixed_block_modes[0] < 0;
-        for (int b = 0; b < 3; b++) {
-          const int m = o.fixed_block_modes[b];
-          if (detect) { d->modes[b] = -1; continue; }
-          if (m < 0 || m > (b == 2 ? 3 : 2))
-            return fail(C1_ERR_ARG, "fixed_block_modes[%d] = %d is outside 0..%d", b, m, b == 2 ? 3 : 2);
-          d->modes[b] = m;
-        }
-        (void)probe;
-        return C1_OK;
-      }
-  }
-  const int rc = build_encode_opts_uncached(o, d);
-  if (rc == C1_OK) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (cache.size() >= 8) cache.erase(cache.begin());
-    Entry e;
-    memcpy(e.biased, o.biased_scale_factors, sizeof e.biased);
-    e.opts = *d;
-    cache.push_back(e);
-  }
-  return rc;
-}
-int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
-  memset(d, 0, sizeof *d);
-  for (int i = 0; i < 64; i++) {
-    if (!std::isfinite(o.biased_scale_factors[i]) || o.biased_scale_factors[i] < 0)
-      return fail(C1_ERR_ARG, "biased_scale_factors[%d] is not a finite non-negative number", i);
-    d->biased[i] = o.biased_scale_factors[i];
-  }
+// C1DevEncOpts = the fields of this call (threshold, block modes: fill_call_fields, run on every call) + what derives from
+// the biased scale-factor table alone (the table itself, its log2 line, the rank tables and their integer form:
+// build_table_fields).  The search for an integer form costs ~30 M host operations when there is none, so the last few
+// table-derived parts are kept; nothing that depends on another option may live in that cache.
+int fill_call_fields(const c1_encode_options &o, C1DevEncOpts *d) {
   if (std::isnan(o.transient_threshold)) return fail(C1_ERR_ARG, "transient_threshold is NaN");
   d->threshold = o.transient_threshold;
   const bool detect = o.fixed_block_modes[0] < 0;
@@ -301,14 +261,49 @@ int build_encode_opts_uncached(const c1_encode_options &o, C1DevEncOpts *d) {
       return fail(C1_ERR_ARG, "fixed_block_modes[%d] = %d is outside 0..%d", b, m, b == 2 ? 3 : 2);
     d->modes[b] = m;
   }
+  static const int no_tonal = getenv("C1_ALLOC_NO_TONAL") ? atoi(getenv("C1_ALLOC_NO_TONAL")) : 0;
+  d->alloc_no_tonal = no_tonal;                          // experiments: 1 = always run the 52-BFU candidate first
+  return C1_OK;
+}
+
+int build_table_fields(const c1_encode_options &o, C1DevEncOpts *d);
+
+int build_encode_opts(const c1_encode_options &o, C1DevEncOpts *d) {
+  struct Entry { double biased[64]; C1DevEncOpts table_part; };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  bool hit = false;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry &e : cache)
+      if (memcmp(e.biased, o.biased_scale_factors, sizeof e.biased) == 0) { *d = e.table_part; hit = true; break; }
+  }
+  if (!hit) {
+    const int rc = build_table_fields(o, d);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    Entry e;
+    memcpy(e.biased, o.biased_scale_factors, sizeof e.biased);
+    e.table_part = *d;
+    cache.push_back(e);
+  }
+  return fill_call_fields(o, d);
+}
+
+int build_table_fields(const c1_encode_options &o, C1DevEncOpts *d) {
+  memset(d, 0, sizeof *d);
+  for (int i = 0; i < 64; i++) {
+    if (!std::isfinite(o.biased_scale_factors[i]) || o.biased_scale_factors[i] < 0)
+      return fail(C1_ERR_ARG, "biased_scale_factors[%d] is not a finite non-negative number", i);
+    d->biased[i] = o.biased_scale_factors[i];
+  }
   {
     // log2 of the biased table as a line in the index (exact for pow(2^(s/3-21), bias)); see C1DevEncOpts
     const double l1 = std::log2(d->biased[1]), l63 = std::log2(d->biased[63]);
     const double slope = (l63 - l1) / 62.0;
     d->la_slope = (std::isfinite(slope) && std::isfinite(l1)) ? (float)slope : 0.0f;
     d->la_off = (std::isfinite(slope) && std::isfinite(l1)) ? (float)(l1 - slope) : 0.0f;
-    static const int no_tonal = getenv("C1_ALLOC_NO_TONAL") ? atoi(getenv("C1_ALLOC_NO_TONAL")) : 0;
-    d->alloc_no_tonal = no_tonal;                        // experiments: 1 = always run the 52-BFU candidate first
   }
   float pri[64 * 15];
   std::vector<float> uniq;
@@ -421,7 +416,7 @@ struct c1_ctx {
   // context's stream; the two chunks work on different halves of the workspace.  ev_main[p] / ev_tail[p]: main part /
   // tail of the chunk that last used half p.  tail_pending: a tail is in flight that the context's stream has not
   // been made to wait for yet (join_tail); every entry point but the device encode joins before it does anything.
-  bool overlap = true;
+  bool overlap = false;
   hipStream_t s_tail = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
   bool tail_used[2] = {false, false};
@@ -994,8 +989,11 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&ctx->ev_tail[p], hipEventDisableTiming);
     }
     if (pe != hipSuccess) { c1_ctx_destroy(ctx); return fail(C1_ERR_HIP, "tail stream: %s", hipGetErrorString(pe)); }
-    const char *ov = getenv("C1_OVERLAP");      // experiments: 0 = the exact redo on the context's stream, in line
-    ctx->overlap = ov ? atoi(ov) != 0 : true;
+    // C1_OVERLAP=1: the exact redo of a chunk on the tail stream, beside the next chunk's (or call's) analysis.  Off by default:
+    // measured +1.3 % (white noise) to +2.7 % (mixed corpus) -- the redo is mostly real work that the analysis beside it pays
+    // for -- at the price of per-kernel times that include each other
+    const char *ov = getenv("C1_OVERLAP");
+    ctx->overlap = ov ? atoi(ov) != 0 : false;
     const char *pl = getenv("C1_PIPELINE");
     ctx->pipeline = pl ? atoi(pl) != 0 : false;   // measured: no gain while one kernel's grid already owns every CU's LDS
   }

@@ -203,3 +203,44 @@ def test_halo_and_unaligned_runs(ctx):
         part = ctx.encode([c[(f0 - halo) * 512:f1 * 512] for c in chans], opts, halo_frames=halo)
         assert np.array_equal(part, whole[2 * f0:2 * f1]), (f0, f1, halo)
     ctx.set_speculation(1)
+
+
+def test_tail_overlap_mode_is_bit_identical_and_keeps_stream_order():
+    """C1_OVERLAP=1: the exact redo of a chunk runs on a second stream beside the next chunk's / call's analysis.  Several
+    device encodes enqueued back to back without synchronising -- into separate buffers, and into ONE buffer reused call
+    after call (the later call's bytes must stand) -- then one synchronise: every result equals the in-line mode's."""
+    import os
+    import torch
+    import carta1_amd as c1
+    frames = 5000
+    srcs = [[O.gen_white(31, frames * 512), O.gen_pinkT(32, frames * 512)],
+            [O.gen_pinkT(33, frames * 512), O.gen_white(34, frames * 512)],
+            [np.concatenate([O.gen_white(35, 2500 * 512), tone(2500, 700.0, 0.5)]), O.gen_white(36, frames * 512)]]
+    opts = c1.EncoderOptions(LONG)
+    plain = c1.Context(0)
+    want = [plain.encode(s, opts).copy() for s in srcs]
+    plain.close()
+    os.environ['C1_OVERLAP'] = '1'
+    os.environ['C1_CHUNK_FRAMES'] = '1024'                    # several chunks per call: the tails overlap inside a call too
+    try:
+        ctx = c1.Context(0)
+    finally:
+        del os.environ['C1_OVERLAP'], os.environ['C1_CHUNK_FRAMES']
+    dev = [[torch.from_numpy(ch).cuda() for ch in s] for s in srcs]
+    outs = [torch.zeros(frames * 2 * 212, dtype=torch.uint8, device='cuda') for _ in srcs]
+    shared = torch.zeros(frames * 2 * 212, dtype=torch.uint8, device='cuda')
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for d, o in zip(dev, outs):
+            ctx.encode_device([t.data_ptr() for t in d], frames, o.data_ptr(), opts)
+        for d in dev:                                          # the same output buffer, call after call: the last one wins
+            ctx.encode_device([t.data_ptr() for t in d], frames, shared.data_ptr(), opts)
+    ctx.synchronize()
+    for o, w in zip(outs, want):
+        assert np.array_equal(o.cpu().numpy().reshape(-1, 212), w)
+    assert np.array_equal(shared.cpu().numpy().reshape(-1, 212), want[-1])
+    # the host-resident entry points join the tail themselves
+    assert np.array_equal(ctx.encode(srcs[0], opts), want[0])
+    u, r = ctx.speculation_stats()
+    assert u > 0 and r > 0
+    ctx.close()
