@@ -142,7 +142,7 @@ __device__ __forceinline__ void radix4_round(v2f (&x)[4], v2f wa, v2f wb, v2f wa
 
 // Material-local speculation.  How many decisions of this unit will the guards leave open?  The greedy
 // allocation (bitallocation.js:203-281) levels biasedSF 2^-bits over the BFUs it codes, so with L the log2 of that
-// level -- the root of sum size_b clamp(lb_b - L, 0, 16) = budget, found by Newton steps from the left on a convex
+// level -- the root of sum size_b clamp(lb_b - L, 0, 16) = budget, approached from the left by a Newton step on a convex
 // piecewise-linear function -- a coefficient of BFU b is quantized with norm ~ 2^(bits_b - 1) / SF_b and its truncation
 // is doubtful with probability ~ 2 eps norm; a scale-factor index is open with probability ~ 2 eps / (0.206 SF_b).
 // The sum P of those probabilities predicts the flagged fraction 1 - exp(-P) (tools/spec_predictor_sim.py: white noise
@@ -163,8 +163,8 @@ __device__ __attribute__((noinline)) bool spec_should_defer(const uint8_t *sfi, 
   const float n_all = wave_sum(sz);
   if (!(n_all > 0.0f)) return false;                                   // nothing coded: nothing to doubt
   float Lw = (wave_sum(sz * lb) - kBudget) * __builtin_amdgcn_rcpf(n_all);
-#pragma unroll 1
-  for (int it = 0; it < 3; it++) {
+  {
+    // one Newton step (the BFUs the first guess leaves without bits drop out); further steps move P by less than 1 %
     const float d = lb - Lw;
     const float bits = fminf(fmaxf(d, 0.0f), 16.0f);
     const float spend = wave_sum(sz * bits);

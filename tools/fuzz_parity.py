@@ -37,6 +37,7 @@ def main():
         opts['allocationBias'] = bias
         want, _ = O.encode_stream(chs, fixed_modes=opts.get('fixedBlockModes'), bias=bias, threshold=opts.get('transientThresholdLow', 1.0))
         eo = c1.EncoderOptions(opts, biased_table=O.biased_table(bias))
+        ctx.set_speculation(int(rng.choice([0, 1, 1, 2])))      # exact only / material-local / always speculate
         got = ctx.encode(chs, eo)
         assert np.array_equal(got, want), ('units', k, frames, nch, opts)
         # a random split point: the tail encoded from its halo
@@ -44,6 +45,10 @@ def main():
         h = min(2, cut)
         tail = ctx.encode([c[(cut - h) * 512:] for c in chs], eo, halo_frames=h)
         assert np.array_equal(tail, want.reshape(frames, nch, 212)[cut:].reshape(-1, 212)), ('halo', k, cut, opts)
+        if rng.randint(0, 4) == 0:                              # units no encoder wrote: a few flipped bytes
+            want = want.copy()
+            for _ in range(8):
+                want[rng.randint(0, want.shape[0]), rng.randint(0, 212)] ^= np.uint8(rng.randint(1, 256))
         pcm_want, _ = O.decode_stream(want, nch)
         pcm = ctx.decode(want, nch)
         for c in range(nch):
