@@ -93,6 +93,7 @@ __device__ __forceinline__ int bfu_of_slot(int p) {
 }
 
 __device__ __forceinline__ float f32(double x) { return (float)x; }  // Float32Array store
+typedef float v4f __attribute__((ext_vector_type(4)));    // for __builtin_nontemporal_store of 16 bytes
 
 // ECMAScript ToInt32 of a double (what `| 0` does): truncate, wrap modulo 2^32.
 __device__ __forceinline__ int32_t to_int32(double x) {

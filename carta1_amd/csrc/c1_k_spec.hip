@@ -559,10 +559,11 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     // ---------------- the bound, coefficients out, scale-factor indices with their guard ----------------
     const int64_t unit = f * L.channels + ch;
     {
-      float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
-      const float4 *src = reinterpret_cast<const float4 *>(coef);
-      dst[lane] = src[lane];
-      dst[64 + lane] = src[64 + lane];
+      // streaming stores (the packing kernel reads these 4 GB long after they have left the cache): -2 % of the kernel
+      v4f *dst = reinterpret_cast<v4f *>(L.coefs + (unit << 9));
+      const v4f *src = reinterpret_cast<const v4f *>(coef);
+      __builtin_nontemporal_store(src[lane], &dst[lane]);
+      __builtin_nontemporal_store(src[64 + lane], &dst[64 + lane]);
     }
     // eps_b = cz_b Z_b + cw_b W + cl_b L + eabs  (DESIGN.md 3b); Z_b^2 = energy of the band's pre-twiddled points
     // (short blocks: of the block with the most energy; the coefficients then belong to 16-point transforms)
