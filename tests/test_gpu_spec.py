@@ -244,3 +244,40 @@ def test_tail_overlap_mode_is_bit_identical_and_keeps_stream_order():
     u, r = ctx.speculation_stats()
     assert u > 0 and r > 0
     ctx.close()
+
+
+def test_device_encode_only_enqueues():
+    """c1_encode_device never waits for the device (round 2's adaptive mode read counters back on entry): three 262144-frame
+    encodes, each some 2 ms of kernels, are enqueued in a fraction of the time the device needs for one of them -- in the
+    default mode, on tonal material too (where round 2 looked at the previous call's redo fraction), and the results are
+    those of calls made one by one"""
+    import time
+    import torch
+    import carta1_amd as c1
+    frames = 262144
+    ctx = c1.Context(0)
+    opts = c1.EncoderOptions(LONG)
+    pcm = [torch.empty(frames * 512, dtype=torch.float32, device='cuda') for _ in range(2)]
+    torch.cuda.synchronize()
+    ctx.generate_device(c1.SIGNAL_MIXED, 5, frames, pcm[0].data_ptr())
+    ctx.generate_device(c1.SIGNAL_PARTIALS, 6, frames, pcm[1].data_ptr())
+    outs = [torch.zeros(frames * 2 * 212, dtype=torch.uint8, device='cuda') for _ in range(3)]
+    ptrs = [p.data_ptr() for p in pcm]
+    ctx.encode_device(ptrs, frames, outs[0].data_ptr(), opts)      # first call: workspace allocation, options upload
+    ctx.synchronize()
+    want = outs[0].clone()
+    t0 = time.perf_counter()
+    ctx.encode_device(ptrs, frames, outs[0].data_ptr(), opts)
+    ctx.synchronize()
+    one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for o in outs:
+        ctx.encode_device(ptrs, frames, o.data_ptr(), opts)
+    enqueue = time.perf_counter() - t0
+    ctx.synchronize()
+    total = time.perf_counter() - t0
+    assert enqueue < 0.5 * one, (enqueue, one, total)               # three calls enqueued in less than half of one call's run time
+    assert total > 2.0 * one                                       # ... and the device did need its time for them
+    for o in outs:
+        assert torch.equal(o, want)
+    ctx.close()
