@@ -346,27 +346,38 @@ class Context:
             1 if all_long else 0, C.c_void_p(units_out_ptr), C.c_void_p(lists_ptr)))
 
 
-def encode_multi(channels, options=None, devices=(0,)):
+def encode_multi(channels, options=None, devices=(0,), out=None):
     """c1_encode_batch_multi: the batch sharded over `devices` (contiguous frame ranges, one host thread and context
-    per entry, no collective).  channels: a stream from its start.  Same bytes as one device produces."""
+    per entry, no collective).  channels: a stream from its start.  Same bytes as one device produces.
+    out: a C-contiguous uint8 array of frames * channels * 212 bytes to write into (as Context.encode takes)."""
     opts = (options or EncoderOptions()).to_c()
     chans = [np.ascontiguousarray(c, dtype=np.float32) for c in channels]
     n = len(chans[0])
     if any(len(c) != n for c in chans) or n % 512:
         raise ValueError('channels must have equal length, a multiple of 512')
     frames = n // 512
-    units = np.zeros((frames * len(chans), 212), dtype=np.uint8)
+    if out is None:
+        units = np.zeros((frames * len(chans), 212), dtype=np.uint8)
+    else:
+        units = out
+        if units.dtype != np.uint8 or not units.flags.c_contiguous or units.size != frames * len(chans) * 212:
+            raise ValueError('out must be a C-contiguous uint8 array of frames * channels * 212 bytes')
     devs = (C.c_int * len(devices))(*[int(d) for d in devices])
     capi.check(capi.load().c1_encode_batch_multi(devs, len(devices), capi.ptr_array([c.ctypes.data for c in chans]),
                                                  len(chans), frames, 0, C.byref(opts), units.ctypes.data))
     return units
 
 
-def decode_multi(units, channels, devices=(0,)):
-    """c1_decode_batch_multi: units of a stream from its start -> list of float32 arrays."""
+def decode_multi(units, channels, devices=(0,), out=None):
+    """c1_decode_batch_multi: units of a stream from its start -> list of float32 arrays (out: such a list to write into)."""
     u = np.ascontiguousarray(units, dtype=np.uint8).reshape(-1, 212)
     frames = u.shape[0] // channels
-    outs = [np.zeros(frames * 512, dtype=np.float32) for _ in range(channels)]
+    if out is None:
+        outs = [np.zeros(frames * 512, dtype=np.float32) for _ in range(channels)]
+    else:
+        outs = list(out)
+        if len(outs) != channels or any(o.dtype != np.float32 or not o.flags.c_contiguous or o.size != frames * 512 for o in outs):
+            raise ValueError('out must be one C-contiguous float32 array of frames * 512 samples per channel')
     devs = (C.c_int * len(devices))(*[int(d) for d in devices])
     capi.check(capi.load().c1_decode_batch_multi(devs, len(devices), u.ctypes.data, channels, frames, 0,
                                                  capi.ptr_array([o.ctypes.data for o in outs])))

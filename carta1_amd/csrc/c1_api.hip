@@ -1497,13 +1497,6 @@ int c1_pack_spec_tap_device(c1_ctx *ctx, const float *coefs, const float *eps, c
 namespace {
 constexpr int64_t kStreamChunkFrames = 32768;   // frames per channel per chunk of the streamed host path
 
-bool is_pinned_host(const void *p) {
-  hipPointerAttribute_t a;
-  memset(&a, 0, sizeof a);
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return a.type == hipMemoryTypeHost;
-}
-
 int ensure_ring(c1_ctx *ctx, size_t bytes) {
   if (!ctx->s_up) {
     HIP_TRY(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
@@ -1663,11 +1656,12 @@ int c1_encode_batch(c1_ctx *ctx, const float *const *pcm, int channels, int64_t 
   if (frames < 0 || halo_frames < 0 || halo_frames > 2) return fail(C1_ERR_ARG, "bad frames / halo_frames");
   if (frames == 0) return C1_OK;
   if (!pcm || !units) return fail(C1_ERR_ARG, "pcm or units is NULL");
-  {
-    // the PCM is 95 % of the traffic: page-locked PCM is what makes streaming worthwhile
-    bool pinned = frames > kStreamChunkFrames;
-    for (int c = 0; c < channels && pinned; c++) pinned = pcm[c] && is_pinned_host(pcm[c]);
-    if (pinned) return encode_batch_streamed(ctx, pcm, channels, frames, halo_frames, opts, units);
+  if (frames > 2 * kStreamChunkFrames) {
+    // large batches are streamed in chunks (upload | kernels | download on three streams), from page-locked memory at the
+    // link's rate (12.9 M stereo frames/s), from pageable memory nearly so (11.8 M: the runtime stages those copies, but the
+    // chunks keep the stages of the pipeline busy; copy - compute - copy in one piece managed 8.1 M)
+    for (int c = 0; c < channels; c++) if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    return encode_batch_streamed(ctx, pcm, channels, frames, halo_frames, opts, units);
   }
   const size_t ch_bytes = (size_t)(frames + halo_frames) * 512 * sizeof(float);
   const size_t unit_bytes = (size_t)frames * channels * C1_UNIT_BYTES;
@@ -1725,10 +1719,9 @@ int c1_decode_batch(c1_ctx *ctx, const uint8_t *units, int channels, int64_t fra
   if (frames < 0 || halo_units < 0 || halo_units > 1) return fail(C1_ERR_ARG, "bad frames / halo_units");
   if (frames == 0) return C1_OK;
   if (!units || !pcm) return fail(C1_ERR_ARG, "units or pcm is NULL");
-  {
-    bool pinned = frames > kStreamChunkFrames;
-    for (int c = 0; c < channels && pinned; c++) pinned = pcm[c] && is_pinned_host(pcm[c]);
-    if (pinned) return decode_batch_streamed(ctx, units, channels, frames, halo_units, pcm);
+  if (frames > 2 * kStreamChunkFrames) {
+    for (int c = 0; c < channels; c++) if (!pcm[c]) return fail(C1_ERR_ARG, "pcm[%d] is NULL", c);
+    return decode_batch_streamed(ctx, units, channels, frames, halo_units, pcm);
   }
   const size_t halo_bytes = (size_t)halo_units * channels * C1_UNIT_BYTES;   // multiple of 4
   const size_t unit_bytes = (size_t)frames * channels * C1_UNIT_BYTES + halo_bytes;
@@ -1800,20 +1793,6 @@ struct ShardLease {           // the contexts of one *_multi call
   }
 };
 
-// Host memory of the caller pinned in place for the duration of a call (hipHostRegister), so that every shard streams its
-// range at the page-locked PCIe rate without the caller having allocated through c1_host_alloc.  Memory that is page-locked
-// already, or that the runtime declines to register, is left as it is (the shards then copy, compute, copy).
-struct ScopedHostPin {
-  std::vector<void *> pinned;
-  void pin(const void *p, size_t bytes) {
-    static const bool off = getenv("C1_NO_HOST_REGISTER") != nullptr;
-    if (off || !p || bytes < ((size_t)1 << 20) || is_pinned_host(p)) return;
-    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) pinned.push_back(const_cast<void *>(p));
-    else (void)hipGetLastError();
-  }
-  ~ScopedHostPin() { for (void *p : pinned) (void)hipHostUnregister(p); }
-};
-
 // contiguous ranges whose sizes differ by at most one frame
 void shard_plan(int64_t frames, int shards, std::vector<std::pair<int64_t, int64_t>> *plan) {
   const int64_t base = frames / shards, extra = frames % shards;
@@ -1841,13 +1820,6 @@ int c1_encode_batch_multi(const int *devices, int n_devices, const float *const 
   ShardLease lease;
   if ((rc = lease.take(devices, shards))) return rc;
   const std::vector<c1_ctx *> &ctxs = lease.ctxs;
-  // One registration per buffer, made here before the shards start and dropped after they have all finished: the shards'
-  // ranges (and their halos) overlap at page granularity, so they cannot pin their own parts independently.
-  ScopedHostPin pin;
-  if (hipSetDevice(ctxs[0]->device) == hipSuccess) {
-    for (int c = 0; c < channels; c++) pin.pin(pcm[c] - (size_t)halo_frames * 512, (size_t)(frames + halo_frames) * 512 * sizeof(float));
-    pin.pin(units, (size_t)frames * channels * C1_UNIT_BYTES);
-  }
   std::vector<int> rcs(shards, C1_OK);
   std::vector<std::string> errs(shards);
   std::vector<std::thread> threads;
@@ -1881,11 +1853,6 @@ int c1_decode_batch_multi(const int *devices, int n_devices, const uint8_t *unit
   ShardLease lease;
   if ((rc = lease.take(devices, shards))) return rc;
   const std::vector<c1_ctx *> &ctxs = lease.ctxs;
-  ScopedHostPin pin;
-  if (hipSetDevice(ctxs[0]->device) == hipSuccess) {
-    pin.pin(units - (size_t)halo_units * channels * C1_UNIT_BYTES, (size_t)(frames + halo_units) * channels * C1_UNIT_BYTES);
-    for (int c = 0; c < channels; c++) pin.pin(pcm[c], (size_t)frames * 512 * sizeof(float));
-  }
   std::vector<int> rcs(shards, C1_OK);
   std::vector<std::string> errs(shards);
   std::vector<std::thread> threads;
