@@ -257,6 +257,45 @@ __device__ __forceinline__ void sf_long(const float *coef, uint8_t *sfi_out, con
   if (g.store) sfi_out[g.b] = (uint8_t)sfi;
 }
 
+// ---- the same scan of an all-long unit from three 16-byte reads (c1_k_spec.hip) ---------------------------------
+// A lane's <= 12 coefficients (sf_long_geometry: BFU b = lane below 44, half a 20-coefficient BFU above) lie in the three
+// aligned groups of four that start at group src >> 2.  Which of those twelve elements belong to the lane's BFU depends
+// on the lane alone, so "element k is inside" is a set of lanes known at compile time: it is used as the EXEC mask of
+// one v_max_f32.  Against twelve 4-byte reads at lane-varying strides (4- to 8-way bank conflicts, an address select
+// each): 3 LDS instructions instead of 12, 12 vector instructions instead of ~36, 24 scalar moves.
+constexpr int kSpecsC[52] = {8, 8, 8, 8, 4,  4,  4,  4,  8,  8,  8,  8,  6,  6,  6,  6,  6,  6,  6,  6,  6,  6,  6,  6,  7,  7,
+                             7, 7, 9, 9,  9,  9,  10, 10, 10, 10, 12, 12, 12, 12, 12, 12, 12, 12, 20, 20, 20, 20, 20, 20, 20, 20};
+constexpr uint64_t sf_lane_mask(int k) {
+  uint64_t m = 0;
+  for (int lane = 0; lane < 60; lane++) {
+    const bool wide = lane >= 44;
+    const int b = wide ? 44 + ((lane - 44) >> 1) : lane;
+    int start = 0;
+    for (int i = 0; i < b; i++) start += kSpecsC[i];          // BFU_START_LONG = prefix sums of the sizes (constants.js:38-44)
+    const int src = start + (wide ? 10 * (lane & 1) : 0), cnt = wide ? 10 : kSpecsC[b];
+    const int idx = 4 * (src >> 2) + k;
+    if (idx >= src && idx < src + cnt) m |= 1ull << lane;
+  }
+  return m;
+}
+#define C1_SF_STEP(K) "s_mov_b32 exec_lo, %[l" #K "]\n\ts_mov_b32 exec_hi, %[h" #K "]\n\tv_max_f32_e64 %[a], %[a], |%[x" #K "]|\n\t"
+#define C1_SF_MASK(K) [l##K] "n"((uint32_t)sf_lane_mask(K)), [h##K] "n"((uint32_t)(sf_lane_mask(K) >> 32))
+__device__ __forceinline__ float sf_scan_long_groups(float4 q0, float4 q1, float4 q2) {
+  float mx = 0.0f;
+  uint64_t saved;
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               C1_SF_STEP(0) C1_SF_STEP(1) C1_SF_STEP(2) C1_SF_STEP(3) C1_SF_STEP(4) C1_SF_STEP(5)
+               C1_SF_STEP(6) C1_SF_STEP(7) C1_SF_STEP(8) C1_SF_STEP(9) C1_SF_STEP(10) C1_SF_STEP(11)
+               "s_mov_b64 exec, %[sv]"
+               : [a] "+v"(mx), [sv] "=&s"(saved)
+               : [x0] "v"(q0.x), [x1] "v"(q0.y), [x2] "v"(q0.z), [x3] "v"(q0.w), [x4] "v"(q1.x), [x5] "v"(q1.y), [x6] "v"(q1.z),
+                 [x7] "v"(q1.w), [x8] "v"(q2.x), [x9] "v"(q2.y), [x10] "v"(q2.z), [x11] "v"(q2.w),
+                 C1_SF_MASK(0), C1_SF_MASK(1), C1_SF_MASK(2), C1_SF_MASK(3), C1_SF_MASK(4), C1_SF_MASK(5),
+                 C1_SF_MASK(6), C1_SF_MASK(7), C1_SF_MASK(8), C1_SF_MASK(9), C1_SF_MASK(10), C1_SF_MASK(11));
+  return mx;
+}
+static_assert(sf_lane_mask(0) != 0 && (sf_lane_mask(0) >> 60) == 0, "lanes 60..63 own no BFU");
+
 // ---- long-block MDCT core, radix-4 rounds -------------------------------------------------------------
 // The three long transforms of a frame (64, 64 and 128 complex points) run side by side: lanes 0..15 own
 // band 0, 16..31 band 1, 32..63 band 2, four points per lane.  The reference's radix-2 stages (fft.js:41-66)

@@ -580,10 +580,19 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     {
       SfLong SFL = SFL0;
       asm volatile("" : "+v"(SFL.src), "+v"(SFL.cnt));
-      const float *src = coef + SFL.src;
       float mx = 0.0f;
+#ifdef ABL_OLD_SFSCAN
+      if constexpr (true) {
+#else
+      if constexpr (SHORT) {
+#endif
+        const float *src = coef + SFL.src;
 #pragma unroll
-      for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < SFL.cnt ? j : SFL.cnt - 1]));
+        for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < SFL.cnt ? j : SFL.cnt - 1]));
+      } else {
+        const float4 *grp = reinterpret_cast<const float4 *>(coef + (SFL.src & ~3));
+        mx = sf_scan_long_groups(grp[0], grp[1], grp[2]);
+      }
       const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false));
       mx = fmaxf(mx, SFL.wide ? other : 0.0f);
       const float e = SFL.b >= 36 ? e2 : (SFL.b >= 20 ? e1 : e0);
