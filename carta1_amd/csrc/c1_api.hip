@@ -388,23 +388,12 @@ struct c1_ctx {
   // running totals on the device: [0] units that stayed with the speculative analysis, [1] units among them redone exactly,
   // [2] units of exact coefficients quantized in binary32, [3] units among them packed again, [4] units the speculative
   // detector decided, [5] units among them rechecked, [6] units the speculative analysis handed to the exact kernels.
-  // h_totals is a page-locked mirror the totals kernel refreshes: the encode entry reads it WITHOUT synchronising
-  // (the adaptive switches below are heuristics; a value that lags by a call or two serves them as well)
+  // Statistics only (c1_ctx_*_stats): no decision of the encode path reads them.
   unsigned long long *d_spec_totals = nullptr;
-  volatile unsigned long long *h_totals = nullptr;
-  unsigned long long *h_totals_dev = nullptr;    // device address of h_totals
   int spec_mode = 1;                             // 0 exact only, 1 material-local (default), 2 always speculate
   float spec_defer = 1.0f;                       // mode 1: predicted open decisions per unit past which a run goes to the exact kernels
   bool decode_binary32 = false;                  // c1_ctx_set_decode_precision: opt-in binary32 decoder
   bool spec_tables_ok = false;
-  // binary32 quantization of exact coefficients (the exact paths' packing): the same bookkeeping, d_spec_totals[2..3]
-  double q32_last_fraction = 0.0;
-  int q32_off_calls = 0;
-  unsigned long long q32_seen[2] = {0, 0};
-  // speculative transient detector: d_spec_totals[4] units decided, [5] of them by the exact recheck
-  double det_last_fraction = 0.0;
-  int det_off_calls = 0;
-  unsigned long long det_seen[2] = {0, 0};
   // transient-detection workspace (allocated on first use): band samples, feature sums, block modes
   int64_t det_units = 0;
   float *d_bands[2] = {nullptr, nullptr};
@@ -659,26 +648,12 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   bool quantize32 = !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;   // exact coefficients, binary32 quantization with the guard (below)
   static const bool det_spec_env_off = getenv("C1_DETECT_SPEC") && atoi(getenv("C1_DETECT_SPEC")) == 0;   // experiments: exact detector, the rest as usual
   bool detect_spec = detect && !taps && ctx->spec_tables_ok && ctx->spec_mode != 0 && !det_spec_env_off;   // binary32 transient detector with a score interval
-  if (quantize32 && ctx->spec_mode == 1 && ctx->h_totals) {
-    // adaptive switches of the exact paths: what the calls that have FINISHED so far had to repeat.  Read from the
-    // page-locked mirror without synchronising -- this entry point stays asynchronous on the context's stream.
-    unsigned long long tot[6];
-    for (int i = 0; i < 6; i++) tot[i] = ctx->h_totals[i];
-    const unsigned long long qu = tot[2] - ctx->q32_seen[0], qr = tot[3] - ctx->q32_seen[1];
-    if (qu > 0 && tot[2] >= ctx->q32_seen[0]) { ctx->q32_last_fraction = (double)qr / (double)qu; ctx->q32_off_calls = 0; }
-    ctx->q32_seen[0] = tot[2]; ctx->q32_seen[1] = tot[3];
-    const unsigned long long tu = tot[4] - ctx->det_seen[0], tr = tot[5] - ctx->det_seen[1];
-    if (tu > 0 && tot[4] >= ctx->det_seen[0]) { ctx->det_last_fraction = (double)tr / (double)tu; ctx->det_off_calls = 0; }
-    ctx->det_seen[0] = tot[4]; ctx->det_seen[1] = tot[5];
-    // A listed unit costs two exact transient FFTs where the exact detector spends one per unit: past a fifth of the
-    // units left open the speculative detector is a loss, and such a stream keeps the exact one (probed every 16th call).
-    if (detect_spec && ctx->det_last_fraction > 0.20 && ctx->det_off_calls < 15) { detect_spec = false; ctx->det_off_calls++; }
-    // Material coded with long word lengths (tones: 12-16 bits) leaves binary32 too few fraction bits to certify a
-    // truncation; packing twice is then a loss, so such streams keep the binary64 packing, probed again every 16th call.
-    // (Only where the whole call is exact: a speculative call quantizes the runs it hands to the exact kernels in
-    // binary32 too, unit by unit.)
-    if (!speculate && ctx->q32_last_fraction > 0.10 && ctx->q32_off_calls < 15) { quantize32 = false; ctx->q32_off_calls++; }
-  }
+  // Both shortcuts of the exact paths (binary32 quantization of exact coefficients, binary32 transient detector) are
+  // taken whenever speculation is on; nothing is carried from call to call.  What they hand back to the exact arithmetic
+  // is listed unit by unit inside the call: 0.07 % (noise) to 4 % (stationary partials) of the units packed again, 0.02 to
+  // 0.3 % rechecked (tools/adaptive_probe.py) -- round 2's per-context switches at 10 % and 20 % never fired on any
+  // material tried and made throughput depend on what a context had encoded before.  c1_ctx_set_speculation(ctx, 0)
+  // turns every shortcut off for a stream that is known to defeat them; the bytes are the same either way.
   const bool overlap = speculate && ctx->overlap && ctx->s_tail != nullptr;
   if (!overlap && (rc = join_tail(ctx))) return rc;       // every other path works on the context's stream alone
   const bool piped = ctx->pipeline && !taps && frames > chunk && !speculate;
@@ -766,7 +741,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
         R.unit_list = L.redo_list;
         R.unit_count = L.redo_count;
         c1k_launch_pack(R, all_long_modes, sA);
-        c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), ctx->d_redo[p], 0, sA);
+        c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), ctx->d_redo[p], 0, sA);
       }
       if (overlap) {
         HIP_TRY(hipEventRecord(ctx->ev_tail[p], sT));
@@ -780,7 +755,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       if (all_long) c1k_launch_analysis_long(L, sA);
       else if (detect) {
         c1k_launch_detect(L, ctx->d_bands[p], ctx->d_feat[p], ctx->d_modes[p], ctx->d_lists[p], detect_spec, nullptr, sA);
-        if (detect_spec) c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), ctx->d_lists[p] + 2, 2, sA);
+        if (detect_spec) c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), ctx->d_lists[p] + 2, 2, sA);
         if (L.bands) HIP_TRY(hipMemcpyAsync(L.bands, ctx->d_bands[p] + (size_t)channels * 512, (size_t)n * channels * 512 * sizeof(float),
                                             hipMemcpyDeviceToDevice, sA));
       } else c1k_launch_analysis(L, false, sA);
@@ -806,7 +781,7 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       R.unit_list = L.redo_list;
       R.unit_count = L.redo_count;
       c1k_launch_pack(R, all_long, sB);
-      c1k_launch_spec_totals(ctx->d_spec_totals, ctx->h_totals_dev, (uint64_t)(n * channels), L.redo_count, 1, sB);
+      c1k_launch_spec_totals(ctx->d_spec_totals, (uint64_t)(n * channels), L.redo_count, 1, sB);
     } else if (L.units) { ScopedTiming t(ctx, K_PACK, sB); c1k_launch_pack(L, all_long, sB); }
     if (piped) HIP_TRY(hipEventRecord(ctx->ev_free[p], sB));
   }
@@ -953,16 +928,6 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
   if (me == hipSuccess) me = hipMemcpy(ctx->d_tables, h, sizeof *h, hipMemcpyHostToDevice);
   if (me == hipSuccess) me = hipMalloc(&ctx->d_spec_totals, kTotals * sizeof(unsigned long long));
   if (me == hipSuccess) me = hipMemset(ctx->d_spec_totals, 0, kTotals * sizeof(unsigned long long));
-  if (me == hipSuccess) {
-    void *hp = nullptr, *dp = nullptr;
-    me = hipHostMalloc(&hp, kTotals * sizeof(unsigned long long), hipHostMallocMapped);
-    if (me == hipSuccess) {
-      memset(hp, 0, kTotals * sizeof(unsigned long long));
-      ctx->h_totals = static_cast<volatile unsigned long long *>(hp);
-      me = hipHostGetDevicePointer(&dp, hp, 0);
-      ctx->h_totals_dev = static_cast<unsigned long long *>(dp);
-    }
-  }
   ctx->spec_tables_ok = h->spec_ok != 0;
   {
     const char *sp = getenv("C1_SPEC");       // 0 exact only, 1 material-local (default), 2 always speculate
@@ -1017,7 +982,6 @@ int c1_ctx_destroy(c1_ctx *ctx) {
   if (ctx->d_tables) hipFree(ctx->d_tables);
   if (ctx->d_opts) hipFree(ctx->d_opts);
   if (ctx->d_spec_totals) hipFree(ctx->d_spec_totals);
-  if (ctx->h_totals) (void)hipHostFree(const_cast<unsigned long long *>(ctx->h_totals));
   (void)hipDeviceSynchronize();
   free_workspace(ctx);
   if (ctx->s_tail) (void)hipStreamDestroy(ctx->s_tail);
@@ -1067,10 +1031,6 @@ int c1_ctx_set_speculation(c1_ctx *ctx, int mode) {
   if (mode < 0 || mode > 2) return fail(C1_ERR_ARG, "speculation mode must be 0, 1 or 2, got %d", mode);
   CTX_GUARD(ctx);
   ctx->spec_mode = mode;
-  ctx->q32_last_fraction = 0.0;
-  ctx->q32_off_calls = 0;
-  ctx->det_last_fraction = 0.0;
-  ctx->det_off_calls = 0;
   return C1_OK;
 }
 
@@ -1093,9 +1053,6 @@ int c1_ctx_speculation_stats(c1_ctx *ctx, uint64_t *units, uint64_t *redone, int
   if (reset) {
     HIP_TRY(hipMemsetAsync(ctx->d_spec_totals, 0, kTotals * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_totals) for (int i = 0; i < kTotals; i++) ctx->h_totals[i] = 0;
-    ctx->q32_seen[0] = ctx->q32_seen[1] = 0;
-    ctx->det_seen[0] = ctx->det_seen[1] = 0;
   }
   return C1_OK;
 }

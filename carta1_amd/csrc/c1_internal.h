@@ -187,7 +187,7 @@ void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream)
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream);   // binary32 quantization with the guard band; fills the redo list
 // running totals (c1_ctx::d_spec_totals) and their page-locked mirror; kind 0 speculative call (counts = list head), 1 binary32
 // quantization of exact coefficients (counts[0] = repacked), 2 speculative detector (counts[0] = rechecked)
-void c1k_launch_spec_totals(unsigned long long *totals, unsigned long long *mirror, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream);
+void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream);
 // the speculative kernel's slot array (L.defer_list) -> dense list of deferred runs; counts[0] = entries, counts[1] = units covered
 void c1k_launch_defer_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *counts, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, bool binary32, hipStream_t stream);   // binary32: opt-in, PCM within rounding noise of the reference

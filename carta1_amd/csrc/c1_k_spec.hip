@@ -581,11 +581,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       SfLong SFL = SFL0;
       asm volatile("" : "+v"(SFL.src), "+v"(SFL.cnt));
       float mx = 0.0f;
-#ifdef ABL_OLD_SFSCAN
-      if constexpr (true) {
-#else
       if constexpr (SHORT) {
-#endif
         const float *src = coef + SFL.src;
 #pragma unroll
         for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < SFL.cnt ? j : SFL.cnt - 1]));
@@ -651,8 +647,8 @@ __global__ __launch_bounds__(256) void k_defer_compact(const uint32_t *__restric
 
 // kind 0: a speculative call -- counts = the list head (redo, realloc, re-analysis, deferred runs, deferred units);
 // kind 1: exact coefficients quantized in binary32 -- counts[0] = units packed again;  kind 2: the speculative detector --
-// counts[0] = units rechecked.  mirror: page-locked host memory the encode entry reads without synchronising.
-__global__ void k_spec_totals(unsigned long long *totals, unsigned long long *mirror, unsigned long long units, const uint32_t *counts, int kind) {
+// counts[0] = units rechecked.  Statistics only (c1_ctx_*_stats).
+__global__ void k_spec_totals(unsigned long long *totals, unsigned long long units, const uint32_t *counts, int kind) {
   if (kind == 0) {
     const unsigned long long deferred = counts[4];
     totals[0] += units - deferred;
@@ -667,16 +663,12 @@ __global__ void k_spec_totals(unsigned long long *totals, unsigned long long *mi
     totals[4] += units;
     totals[5] += counts[0];
   }
-  if (mirror) {
-    for (int i = 0; i < 7; i++) mirror[i] = totals[i];
-    __threadfence_system();
-  }
 }
 
 }  // namespace
 
-void c1k_launch_spec_totals(unsigned long long *totals, unsigned long long *mirror, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream) {
-  hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, mirror, (unsigned long long)units, counts, kind);
+void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream) {
+  hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, (unsigned long long)units, counts, kind);
 }
 void c1k_launch_defer_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *counts, hipStream_t stream) {
   const int run = c1k_pick_run(L.frames, L.channels, 0);

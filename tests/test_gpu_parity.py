@@ -268,7 +268,7 @@ def test_edge_cases_against_reference(ctx):
     assert np.array_equal(got, want)
     # the same through the exact paths, whose packing quantizes in binary32 behind a guard band and must hand
     # everything it cannot certify (and anything not finite) to the binary64 kernel
-    ctx.set_speculation(2)                       # not adaptive: the streams before this one may have switched it off
+    ctx.set_speculation(2)
     before = ctx.quantization_stats()
     for opts, fm in (({'fixedBlockModes': [0, 2, 0]}, (0, 2, 0)), ({}, None), ({'transientThresholdLow': 0.1}, None)):
         want, _ = O.encode_stream([wild], fixed_modes=fm, threshold=opts.get('transientThresholdLow', 1.0))
