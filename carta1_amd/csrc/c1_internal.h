@@ -143,10 +143,18 @@ struct C1DecodeLaunch {
 // dispatcher has nothing left to balance) by 5 % (speculative analysis) to 8 % (decode); 32 and 128 are within noise
 // of 64.  C1_RUN_FRAMES overrides it for experiments.
 constexpr int kRunDefault = 64;
+// Small batches (a streaming push, a frame closure) take shorter runs: 64 frames walked by one wave are 64 frames of
+// latency (a 64-frame mono push: 0.41 ms, of which the walk is 0.3) while the rest of the machine idles; the batch is
+// spread over up to 2 048 waves instead, and a run is never shorter than 4 frames (each pays one warm-up frame).
+// A function of the batch alone: every kernel of a call, and the run lists they hand each other, use the same length.
 inline int c1k_pick_run(int64_t frames, int channels, int slots) {
   static const int forced = getenv("C1_RUN_FRAMES") ? atoi(getenv("C1_RUN_FRAMES")) : 0;
-  (void)frames; (void)channels; (void)slots;
-  return forced > 0 ? forced : kRunDefault;
+  (void)slots;
+  if (forced > 0) return forced;
+  const int64_t units = frames * channels;
+  if (units >= (int64_t)kRunDefault * 2048) return kRunDefault;
+  const int run = (int)((units + 2047) / 2048);
+  return run < 4 ? 4 : run;
 }
 // wave slots of the current device for a 64-thread kernel (occupancy x compute units), cached by the caller
 template <class Kernel>

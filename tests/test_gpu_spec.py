@@ -41,6 +41,15 @@ def spec_stages(ctx, chans, modes=(0, 0, 0)):
             side.cpu().numpy().reshape(frames, len(chans), 64))
 
 
+def run_length(frames, channels):
+    """c1k_pick_run (c1_internal.h): 64-frame runs, shorter ones for small batches (latency of a streaming push)"""
+    import os
+    if int(os.environ.get('C1_RUN_FRAMES', '0')) > 0:
+        return int(os.environ['C1_RUN_FRAMES'])
+    units = frames * channels
+    return 64 if units >= 64 * 2048 else max(4, -(-units // 2048))
+
+
 @pytest.mark.parametrize('modes', [(0, 0, 0), (2, 2, 3)], ids=['long', 'short'])
 @pytest.mark.parametrize('name,pcm', list(signals()), ids=[s[0] for s in signals()])
 def test_kernel_equals_its_model_and_stays_within_its_bound(ctx, name, pcm, modes):
@@ -51,12 +60,14 @@ def test_kernel_equals_its_model_and_stays_within_its_bound(ctx, name, pcm, mode
     # frames are processed in runs of 64 with one warm-up frame: the first frame of a later run has seen one frame of
     # history where the model has seen the whole stream, which is the same for these feed-forward filters
     assert np.array_equal(co[:, 0], mco), np.argwhere(co[:, 0] != mco)[:4]
-    # the bound is the model's too, except in the first frame of a run (run lengths depend on the machine): there the
+    # the bound is the model's too, except in the first frame of a run (run lengths depend on the batch size): there the
     # energy of the previous frame's first-stage low band comes from the warm-up frame, whose first 23 outputs saw an
     # empty delay line (they are outside the reach of the unit, so the bound holds with either value)
     ok = np.isfinite(meps)
     close = np.isclose(eps[:, 0, :3], meps, rtol=2e-6, atol=0) | ~ok
-    assert close.all(axis=1).mean() > 0.9
+    run = run_length(co.shape[0], 2)
+    inside = np.arange(co.shape[0]) % run != 0
+    assert close.all(axis=1)[inside].all()
     assert np.allclose(eps[:, 0, :3][ok], meps[ok], rtol=0.2, atol=0)
     ref = M.reference_coefs(pcm, modes)
     err = np.abs(co[:, 0].astype(np.float64) - ref.astype(np.float64))
@@ -186,9 +197,20 @@ def test_material_change_inside_a_run(ctx):
     d = ctx.speculation_deferred()
     want, _ = O.encode_stream([x], fixed_modes=(0, 0, 0))
     assert np.array_equal(got, want)
-    # tones occupy frames 100..199: noticed at the check of frame 112 at the latest (the run 64..127 is left there),
-    # runs 128..191 at their first frame, run 192..255 at 192 and kept to its end although the tone stops at 200
-    assert 100 + 28 <= d <= 100 + 12 + 56 + 16, d
+    # tones occupy frames 100..199.  A run is left at its first check (its first frame, then every 16th) that looks at a
+    # tonal frame, and stays with the exact kernels to its end although the tone may have stopped: with 64-frame runs,
+    # run 64..127 at frame 112, run 128..191 at 128, run 192..255 at 192; the frames at the two edges may go either way
+    run = run_length(300, 1)
+
+    def handed_over(first, last):
+        total = 0
+        for start in range(0, 300, run):
+            end = min(start + run, 300)
+            hit = [c for c in range(start, end, 16) if first <= c <= last]
+            if hit:
+                total += end - hit[0]
+        return total
+    assert handed_over(102, 197) <= d <= handed_over(99, 200), (d, run)
 
 
 def test_halo_and_unaligned_runs(ctx):
