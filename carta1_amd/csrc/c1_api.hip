@@ -351,6 +351,7 @@ int build_table_fields(const c1_encode_options &o, C1DevEncOpts *d) {
 }
 
 constexpr int kTotals = 8;                             // running totals of a context (c1_ctx::d_spec_totals)
+constexpr int64_t kSpecMinUnits = 64;                  // default mode: calls below this many sound units use the exact kernels only
 constexpr int kListHead = 8;                           // uint32 counters in front of the speculative path's lists
 constexpr int64_t kMaxChunkFrames = (int64_t)1 << 27;   // x 2 channels = 2^28 units per chunk < 2^29
 
@@ -648,6 +649,11 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   bool quantize32 = !taps && units && ctx->spec_tables_ok && ctx->spec_mode != 0;   // exact coefficients, binary32 quantization with the guard (below)
   static const bool det_spec_env_off = getenv("C1_DETECT_SPEC") && atoi(getenv("C1_DETECT_SPEC")) == 0;   // experiments: exact detector, the rest as usual
   bool detect_spec = detect && !taps && ctx->spec_tables_ok && ctx->spec_mode != 0 && !det_spec_env_off;   // binary32 transient detector with a score interval
+  // A call of a few frames (a frame closure, a short streaming push) is bound by the number of launches behind it, and
+  // every speculative shortcut adds some (the redo chain, the recheck, the second packing pass): in the default mode such
+  // calls take the exact kernels (one mono frame: 159 against 185 us, tools/latency_probe.py).  A rule on the size of
+  // this call alone; mode 2 still speculates on anything.
+  if (ctx->spec_mode == 1 && frames * channels < kSpecMinUnits) speculate = quantize32 = detect_spec = false;
   // Both shortcuts of the exact paths (binary32 quantization of exact coefficients, binary32 transient detector) are
   // taken whenever speculation is on; nothing is carried from call to call.  What they hand back to the exact arithmetic
   // is listed unit by unit inside the call: 0.07 % (noise) to 4 % (stationary partials) of the units packed again, 0.02 to

@@ -117,6 +117,8 @@ int c1_ctx_kernel_ms(c1_ctx *ctx, const char *name, double *ms, int *launches);
  * 64-frame run the speculative kernel predicts, from the scale-factor indices and its bound, how many decisions of a
  * unit the guards will leave open, and past a threshold hands the rest of that run to the exact kernels -- the choice
  * is taken per run inside the call, never carried from one call or stream to the next; 2 = always speculate.
+ * In mode 1 a call of fewer than 64 sound units (a frame closure, a short streaming push) uses the exact kernels only:
+ * it is bound by the number of launches behind it, and every shortcut adds some.
  * The environment variable C1_SPEC (0/1/2) sets the default of new contexts. */
 int c1_ctx_set_speculation(c1_ctx *ctx, int mode);
 /* units that stayed with the speculative analysis and units among them that were redone exactly, since the context

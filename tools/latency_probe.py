@@ -4,9 +4,10 @@ sys.path.insert(0, '/root/repo')
 import numpy as np
 import carta1_amd as c1
 ctx = c1.Context(0)
+SIZES = [int(a) for a in sys.argv[1:]] or [1, 8, 64, 512]
 rng = np.random.default_rng(0)
 x = (rng.standard_normal(512) * 0.2).astype(np.float32)
-for frames in (1, 8, 64, 512):
+for frames in SIZES:
     pcm = np.tile(x, frames)
     for mode in (1, 0, 2):
         ctx.set_speculation(mode)
