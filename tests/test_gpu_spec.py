@@ -227,6 +227,38 @@ def test_halo_and_unaligned_runs(ctx):
     ctx.set_speculation(1)
 
 
+@pytest.mark.parametrize('frames,channels', [(2049, 1), (6143, 1), (6145, 2), (20481, 1), (33000, 2), (65537, 1)])
+def test_run_lengths_of_mid_sized_batches(ctx, frames, channels):
+    """c1k_pick_run spreads a batch of fewer than 131 072 units over up to 2 048 waves: run lengths 4..64 that do not
+    divide the batch, in every path that walks runs (speculative, material-local with a tonal stretch across run ends,
+    exact, detection; the decoder).  Bytes equal across the modes and equal the oracle's on the first 1 500 frames; the
+    decoded PCM equals the oracle's there."""
+    import carta1_amd as c1
+    n = frames * 512
+    chans = [np.concatenate([O.gen_white(41 + c, (frames // 3) * 512), tone(frames // 3, 1500.0 + 300 * c, 0.5),
+                             O.gen_pinkT(43 + c, n - 2 * (frames // 3) * 512)]) for c in range(channels)]
+    assert 4 < run_length(frames, channels) <= 64 or frames * channels < 4 * 2048
+    head = 1500
+    for label, o, fm in (('long', LONG, (0, 0, 0)), ('short', {'fixedBlockModes': [2, 2, 3]}, (2, 2, 3)), ('mixed', {'fixedBlockModes': [0, 2, 0]}, (0, 2, 0)), ('detect', {}, None)):
+        opts = c1.EncoderOptions(o)
+        got = {}
+        for mode in (0, 1, 2):
+            ctx.set_speculation(mode)
+            got[mode] = ctx.encode(chans, opts).copy()
+        ctx.set_speculation(1)
+        assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]), label
+        want, _ = O.encode_stream([c[:head * 512] for c in chans], fixed_modes=fm)
+        assert np.array_equal(got[0][:head * channels], want), label
+    pcm = ctx.decode(got[0], channels)
+    want_pcm, _ = O.decode_stream(want, channels)
+    for c in range(channels):
+        assert np.array_equal(pcm[c][:(head - 1) * 512], want_pcm[c][:(head - 1) * 512])
+    # the decoder's runs: a slice that starts inside the batch, from the unit before it
+    part = ctx.decode(got[0][(777 - 1) * channels:], channels, halo_units=1)
+    for c in range(channels):
+        assert np.array_equal(part[c], pcm[c][777 * 512:])
+
+
 def test_tail_overlap_mode_is_bit_identical_and_keeps_stream_order():
     """C1_OVERLAP=1: the exact redo of a chunk runs on a second stream beside the next chunk's / call's analysis.  Several
     device encodes enqueued back to back without synchronising -- into separate buffers, and into ONE buffer reused call
