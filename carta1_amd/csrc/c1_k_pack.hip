@@ -34,7 +34,7 @@ struct alignas(16) PackLds {
   uint32_t desc[52];          // per BFU: bits(5) | mantissa bit offset(11) << 5 | first coefficient(9) << 16
   double normd[52];           // per BFU: quantRange / SCALE_FACTORS[sfi], 0 when nothing is coded
   // speculative path, one 16-byte record per BFU (one ds_read_b128 per mantissa): bits | offset << 5, fl32(norm), the guard
-  // band eps_band * norm (1 + 2^-20) + 2^-22, the quantizer's range 2^(bits-1) - 1
+  // band eps_band * norm (1 + 2^-20) + 2^-22, the quantizer's range 2^(bits-1) - 1 plus one half, as a binary32 number
   alignas(16) uint4 rec[52];
   uint32_t redo[kRedoBatch];  // speculative path: units to redo, appended to the global list a batch at a time
 };
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
         const float g = eb * nf;
         S.rec[lane] = make_uint4((uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5), __float_as_uint(nf),
                                  __float_as_uint(__builtin_fmaf(g, 9.5367431640625e-07f, g) + 2.384185791015625e-07f),
-                                 (uint32_t)((1 << (bits_b > 0 ? bits_b - 1 : 0)) - 1));
+                                 __float_as_uint((float)((1 << (bits_b > 0 ? bits_b - 1 : 0)) - 1) + 0.5f));
       } else {
         S.desc[lane] = (uint32_t)bits_b | ((uint32_t)(16 + 10 * n + scan - mybits) << 5) | ((uint32_t)(mode == 0 ? my_long : my_short) << 16);
         S.normd[lane] = (sf != 0 && bits_b != 0) ? norm_s[sf * 16 + wl] : 0.0;
@@ -246,14 +246,16 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
 #pragma unroll
         for (int m = 2 * p; m < 2 * p + 2; m++) {
           const uint4 r = S.rec[slot_b[m]];
-          const int bits = r.x & 31, range = (int)r.w;
+          const int bits = r.x & 31;
           const float a = __builtin_fmaf(fabsf(x[m]), __uint_as_float(r.y), 0.5f);
           const float d = __builtin_amdgcn_fractf(a);
           const float et = __builtin_fmaf(a, 2.384185791015625e-07f, __uint_as_float(r.z));
           tt[m - 2 * p] = fabsf(d - 0.5f) + et;
-          const int32_t q = (int32_t)__builtin_copysignf(a, x[m]);     // truncation towards zero
-          const int32_t qc = q < -range ? -range : (q > range ? range : q);   // v_med3_i32
-          const uint32_t v = (uint32_t)qc & (uint32_t)(2 * range + 1);
+          // the clamp to +-range (quantization.js:49-53) before the conversion: a >= 1/2, and trunc(min(a, range + 1/2)) =
+          // min(trunc(a), range) for every finite a (range + 1/2 is a binary32 number); the sign rides on the conversion.
+          // (a NaN comes out as +-range instead of 0: its unit is on the redo list anyway, `worst` above)
+          const int32_t qc = (int32_t)__builtin_copysignf(fminf(a, __uint_as_float(r.w)), x[m]);
+          const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)qc, 0u, (uint32_t)bits);
           acc = (acc << bits) | v;
           cnt += bits;
         }

@@ -85,9 +85,11 @@ int pack_model_quantize(const float *slots, const float eps[3], const int sfi[52
       const uint32_t tu = f2u(t);
       if (tu > worst) worst = tu;
       if (doubt_out) doubt_out[first + j] = !(tu < 0x3EFFFFFCu);
-      int32_t q = cvt_i32(copysignf(a, x));
-      q = q < -range ? -range : (q > range ? range : q);
-      q_out[first + j] = q;
+      /* the clamp before the conversion: trunc(min(a, range + 1/2)) = min(trunc(a), range) for every finite a >= 1/2;
+       * v_min_f32 returns the other operand for a NaN */
+      const float rh = (float)range + 0.5f;
+      const float ac = (a != a) ? rh : fminf(a, rh);
+      q_out[first + j] = cvt_i32(copysignf(ac, x));
     }
     first += SPECS[b];
   }
