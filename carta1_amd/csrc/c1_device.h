@@ -39,6 +39,17 @@ __device__ __forceinline__ int lane_for_this_frame(int lane) {
   asm volatile("" : "+v"(lane));
   return lane;
 }
+// The frame-walking kernels run ONE wave per workgroup, and the LDS operations of one wave execute in issue order: all
+// they need between a phase that writes LDS and the next that reads it is that the COMPILER keeps the order.  That is a
+// fence at wavefront scope.  __syncthreads() is a fence at workgroup scope plus a barrier, and the workgroup-scope
+// release makes the compiler wait for every outstanding global access first (s_waitcnt vmcnt(0)): the PCM prefetched
+// for the next frame, the table values requested a round ahead and the coefficient stores of the frame just finished
+// were all waited for at the next fence instead of when (if ever) their registers were needed.
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Always true, but not to the compiler: `if (own_block()) core(); else cheap();` keeps a long unrolled core in a
 // basic block of its own.  Merged into the surrounding block, the scheduler hoists the core's LDS reads over
 // the code before it and the kernel spills (k_analysis_fast: 110 VGPRs and no scratch with, 128 + 49 spills without).

@@ -41,8 +41,12 @@ struct alignas(16) SpecLds {
   alignas(16) float pre2[72];        // what the next frame's band-2 MDCT input starts with: windowed overlap (32), then the 39 delayed samples
   alignas(16) float win[32];         // fl32(WINDOW_SHORT)
   alignas(4) uint8_t sfi[64];
+  // lane-only values of the END of a frame (where the coefficients go, the post-twiddle pair, the scale-factor scan), read
+  // back once per frame instead of being carried in registers through the whole loop: the register allocator spilled four
+  // such values to scratch, and a scratch reload waits on the same counter as the coefficient stores issued just before it
+  uint32_t geo[3][64];
 };
-static_assert(sizeof(SpecLds) <= 6656, "speculative analysis: 24 waves per CU");
+static_assert(sizeof(SpecLds) <= 8192, "speculative analysis: 20 waves per CU");
 constexpr int kE2 = 0, kH2 = 288, kE0 = kR2, kH0 = kR2 + 160, kE1 = kR2 + 288, kH1 = kR2 + 448;
 
 __device__ __forceinline__ int w1_phys(int v) { return 12 * (v >> 3) + (v & 7); }
@@ -220,6 +224,11 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
   if (lane < 16) reinterpret_cast<uint32_t *>(S.sfi)[lane] = 0u;
   const SpecBase B0 = spec_base(lane0);
   const SfLong SFL0 = SHORT ? sf_geometry(lane0, 2, 2, 3) : sf_long_geometry(lane0);
+  if constexpr (!SHORT) {
+    S.geo[0][lane0] = (uint32_t)(SFL0.src & ~3) | ((uint32_t)SFL0.b << 9) | (SFL0.wide ? 1u << 15 : 0u) | (SFL0.store ? 1u << 16 : 0u);
+    S.geo[1][lane0] = (uint32_t)(B0.band0 ? B0.e0 : B0.e1) | ((uint32_t)(B0.band0 ? B0.e1 : B0.e0) << 16);
+    S.geo[2][lane0] = (uint32_t)B0.po0;
+  }
   if (SHORT && lane == 0) S.sfi[52] = (uint8_t)((L.opts->modes[0] & 3) | ((L.opts->modes[1] & 3) << 2) | ((L.opts->modes[2] & 3) << 4));
   // short blocks: lane = (band, block, r) with four points of one 16-point transform
   const int s_band = lane0 < 16 ? 0 : (lane0 < 32 ? 1 : 2);
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
   const int s_c0 = (s_band == 0 ? 0 : (s_band == 1 ? 128 : 256)) + 32 * s_blk + 2 * (s_g & 3);   // coefficient 2 i of the first final point
   const TablesRsrc RT = tables_rsrc(L.tables);
   float p_prev = 0.0f, q_prev = 0.0f;        // PCM / stage-1-low energies of the previous frame
-  __syncthreads();
+  wave_fence();
 
   const int64_t f_end = (f0 + L.run_frames < L.frames) ? f0 + L.run_frames : L.frames;
   int64_t f_first = f0 - 1;                   // one frame of history rebuilds the state
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       const float p = p2.x + p2.y;
       P = wave_sum(p);
     }
-    __syncthreads();
+    wave_fence();
     // ---------------- first QMF stage ----------------
     float Q;
     {
@@ -287,8 +296,11 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
         }
         qmf_core_f32<4>(W, T, lo, hi);
       } else { for (int d = 0; d < 4; d++) { lo[d] = mem[lane + d]; hi[d] = 1.0f; } }
-      if (f + 1 < f_end) {      // the next frame's PCM: requested once the window registers are free, used a frame later
-        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
+      {
+        // the next frame's PCM: requested once the window registers are free, used a frame later.  Unconditional (the
+        // last frame of a run asks for itself again): under a condition the loaded values were copied into the
+        // loop-carried registers right behind the load, i.e. waited for on the spot
+        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
         pre_a = p4[lane]; pre_b = p4[64 + lane];
       }
       if (lane < 46) { S.d1[lane] = mem[w1_phys(512 + lane)]; mem[kR2 + lane] = S.d2[lane]; }
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
         }
       }
     }
-    __syncthreads();
+    wave_fence();
     // ---------------- second QMF stage ----------------
     {
       float lo[2], hi[2];
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     }
     const float W = __builtin_amdgcn_sqrtf(P + p_prev), Lw = __builtin_amdgcn_sqrtf(Q + q_prev);
     p_prev = P; q_prev = Q;
-    __syncthreads();
+    wave_fence();
     if (!emit) continue;
 
     v2f x[4];
@@ -407,7 +419,6 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     SpecBase B = B0;
     asm volatile("" : "+v"(B.ia0), "+v"(B.ic0), "+v"(B.q2), "+v"(B.ib), "+v"(B.id), "+v"(B.pt0));
     asm volatile("" : "+v"(B.za), "+v"(B.zb), "+v"(B.zc), "+v"(B.zd), "+v"(B.g));
-    asm volatile("" : "+v"(B.e0), "+v"(B.e1), "+v"(B.po0));
     {
       const int qb = 4 * B.q2;                               // bytes between the pre-twiddle pairs of points q apart
       const v2f t0 = table_f2(RT, B.pt0), t1 = table_f2(RT, B.pt0 + 2 * qb);
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     }
     const int twb = (int)offsetof(C1DevTables, r4b) + 24 * (B.g & 3);
     const v2f wBa = table_f2(RT, twb), wBb = table_f2(RT, twb + 8), wBc = table_f2(RT, twb + 16);
-    __syncthreads();
+    wave_fence();
     {
       v2f *p = z + B.zb;
       x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     const int twc = (int)offsetof(C1DevTables, r4c) + 24 * (B.g & 15), twd = (int)offsetof(C1DevTables, r2d) + 8 * (B.g & 31);
     const v2f wCa = table_f2(RT, twc), wCb = table_f2(RT, twc + 8), wCc = table_f2(RT, twc + 16);
     const v2f wDa = table_f2(RT, twd), wDb = table_f2(RT, twd + 256);
-    __syncthreads();
+    wave_fence();
     {
       v2f *p = z + B.zc;
       x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
@@ -463,9 +474,11 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     }
     // final points: bands 0/1 hold g + 16 j after round C; band 2 holds g, g + 64, g + 32, g + 96 after round D
     const int d1 = B.band2 ? 64 : 16, d2 = 32, d3 = B.band2 ? 96 : 48;
-    const v2f p0 = table_f2(RT, B.po0), p1 = table_f2(RT, B.po0 + 8 * d1);
-    const v2f p2 = table_f2(RT, B.po0 + 8 * d2), p3 = table_f2(RT, B.po0 + 8 * d3);
-    __syncthreads();
+    const int po0 = (int)S.geo[2][lane];
+    const uint32_t ew = S.geo[1][lane];                      // where -o.x and o.y of the first final point go (band 0: 2 i and n2 - 1 - 2 i; bands 1, 2 reversed)
+    const v2f p0 = table_f2(RT, po0), p1 = table_f2(RT, po0 + 8 * d1);
+    const v2f p2 = table_f2(RT, po0 + 8 * d2), p3 = table_f2(RT, po0 + 8 * d3);
+    wave_fence();
     if (B.band2) {
       const v2f *p = z + B.zd;
       x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
@@ -478,14 +491,14 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     for (int j = 0; j < 4; j++) {
       const v2f t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
       const int dj = j == 0 ? 0 : (j == 1 ? d1 : (j == 2 ? d2 : d3));
-      const int e0 = B.e0 + 2 * dj, e1 = B.e1 - 2 * dj;      // bands 1 and 2 are stored reversed (utils.js:42-48)
+      const int step = B.band0 ? 2 * dj : -2 * dj;           // bands 1 and 2 are stored reversed (utils.js:42-48)
       // mdct.js:110-119: out[2 i] = -(re c + im s), out[n2 - 1 - 2 i] = im c - re s
       const v2f u = x[j].yx * (t.yy * PMN);                  // (im s, -(re s))
       const v2f o = pk_fma(x[j], t.xx, u);
-      coefw[B.band0 ? e0 : e1] = -o.x;
-      coefw[B.band0 ? e1 : e0] = o.y;
+      coefw[(int)(ew & 0xffffu) + step] = -o.x;
+      coefw[(int)(ew >> 16) - step] = o.y;
     }
-    __syncthreads();
+    wave_fence();
 
     }
     float *coef = mem + kR2;
@@ -530,15 +543,15 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       const v2f wBa = table_f2(RT, twb), wBb = table_f2(RT, twb + 8), wBc = table_f2(RT, twb + 16);
       const int po = (int)offsetof(C1DevTables, pre32_64) + 8 * g3;
       const v2f p0 = table_f2(RT, po), p1 = table_f2(RT, po + 32), p2 = table_f2(RT, po + 64), p3 = table_f2(RT, po + 96);
-      __syncthreads();                                     // every lane has read its inputs: the points may overwrite them
+      wave_fence();                                     // every lane has read its inputs: the points may overwrite them
       float4 *dst = reinterpret_cast<float4 *>(z + za);
       dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
       dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
-      __syncthreads();
+      wave_fence();
       const v2f *p = z + zb;
       x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
       radix4_round(x, wBa, wBb, wBc);
-      __syncthreads();
+      wave_fence();
       float *coefw = mem + kR2;
       int c0i = s_c0;
       asm volatile("" : "+v"(c0i));
@@ -553,11 +566,16 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
         coefw[band0 ? e1 : e0] = o.y;
       }
     }
-    __syncthreads();
+    wave_fence();
 
     }
     // ---------------- the bound, coefficients out, scale-factor indices with their guard ----------------
     const int64_t unit = f * L.channels + ch;
+    // The next frame's PCM, requested during the first QMF stage, is taken delivery of HERE, before this frame's stores
+    // are issued: loads and stores share one counter on this part (vmcnt) and return out of order with each other, so a
+    // wait for the PCM placed behind the stores -- where the compiler puts it, at the loop's back edge -- is a wait for
+    // the stores to reach memory as well, once per frame.
+    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
     {
       // streaming stores (the packing kernel reads these 4 GB long after they have left the cache): -2 % of the kernel
       v4f *dst = reinterpret_cast<v4f *>(L.coefs + (unit << 9));
@@ -579,14 +597,18 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     bool unstable;
     {
       SfLong SFL = SFL0;
-      asm volatile("" : "+v"(SFL.src), "+v"(SFL.cnt));
       float mx = 0.0f;
       if constexpr (SHORT) {
+        asm volatile("" : "+v"(SFL.src), "+v"(SFL.cnt));
         const float *src = coef + SFL.src;
 #pragma unroll
         for (int j = 0; j < 12; j++) mx = fmaxf(mx, fabsf(src[j < SFL.cnt ? j : SFL.cnt - 1]));
       } else {
-        const float4 *grp = reinterpret_cast<const float4 *>(coef + (SFL.src & ~3));
+        const uint32_t sw = S.geo[0][lane];
+        SFL.b = (int)((sw >> 9) & 63u);
+        SFL.wide = ((sw >> 15) & 1u) != 0u;
+        SFL.store = ((sw >> 16) & 1u) != 0u;
+        const float4 *grp = reinterpret_cast<const float4 *>(coef + (sw & 0x1ffu));
         mx = sf_scan_long_groups(grp[0], grp[1], grp[2]);
       }
       const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false));
@@ -601,7 +623,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       unstable = lane < 60 && !(s_lo == s_hi && e < __builtin_huge_valf());
     }
     const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;
-    __syncthreads();
+    wave_fence();
     // every kSpecCheckFrames frames: is this material worth speculating on?  If not, the rest of the run (this frame
     // included: nothing of it has been handed on yet but the coefficients, which the exact kernel overwrites) goes to
     // the exact kernels' run list
@@ -610,7 +632,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     }
     if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
     if (lane == 0) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(e0, e1, e2, __int_as_float(any_unstable ? 1 : 0));
-    __syncthreads();
+    wave_fence();
   }
   // one slot per run and channel, written by every workgroup (no list appends: tens of thousands of atomics on one counter
   // serialise at ~6-20 ns each, which cost 0.5 ms per 2 M units when a quarter of the runs were handed over)
