@@ -46,6 +46,8 @@ struct alignas(16) DecodeLds {
   R sf_tab[64];         // SCALE_FACTORS and RN(1/range): lane-varying lookups, kept in LDS (a global load per
   R inv_tab[16];        // coefficient would cost a cache round trip each)
   R step[52];           // per BFU of the unit: SF * RN(1 / range), 0 for a silent BFU (dq_step; the binary32 decoder always)
+  R wtab[32];           // WINDOW_SHORT (the overlap-add's lane-varying lookups: a global load each, waited for on the spot)
+  uint32_t late[8][64]; // all-long frames: imdct_r4's end-of-transform values per lane (see there)
   int16_t dshort[52];   // BFU_START_SHORT[b] - (first slot of b): where a short band's coefficients go, relative to slot order
   union alignas(16) {
     float coef[512];    // dequantized coefficients: dead once the IMDCT pre-twiddle has read them
@@ -151,9 +153,13 @@ __device__ __forceinline__ IMixGeometry imix_geometry(int lane, const FrameModes
 }
 
 // coef: 512 dequantized coefficients; z: 320 slots; mid: 512 outputs.  any_long / band2_long are wave-uniform.
+// late: when not null, the values of the END of the transform (where the outputs go, the post-twiddle pairs) of an
+// all-long frame, one word per lane and value: ox | oy << 16 for j = 0..3 at late[64 j + lane], post_tab at late[256 + 64 j + lane].
+// Carried in registers through the frame loop they push five other values to scratch, and a scratch reload is a
+// vector-memory load: it waits on the counter the unit prefetch and the PCM stores share (see k_decode).
 template <typename RT_>
 __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mid, const IMixGeometry &G, bool any_long,
-                                         bool band2_long, TablesPtr T, TablesRsrc R) {
+                                         bool band2_long, TablesPtr T, TablesRsrc R, const uint32_t *late = nullptr) {
   typedef RT_ real;
   typedef typename Pair2<real>::type pair;
   constexpr bool F32 = std::is_same<real, float>::value;
@@ -186,7 +192,7 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
   pair n0, n1, n2, n3;
   if (any_long) { n0 = table_pair_r<real>(R, G.twc); n1 = table_pair_r<real>(R, G.twc + 16 * kPair); n2 = table_pair_r<real>(R, G.twc + 32 * kPair); n3 = n0; }
   else { n0 = table_pair_r<real>(R, G.post_tab[0]); n1 = table_pair_r<real>(R, G.post_tab[1]); n2 = table_pair_r<real>(R, G.post_tab[2]); n3 = table_pair_r<real>(R, G.post_tab[3]); }
-  __syncthreads();
+  wave_fence();
   {
     float2 *p = z + G.zb;
     x[0] = p[0]; x[1] = p[4]; x[2] = p[8]; x[3] = p[12];
@@ -199,7 +205,7 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
     // round D's twiddles (band 2), in flight during round C
     pair dwa, dwb;
     if (band2_long) { dwa = table_pair_r<real>(R, G.twd); dwb = table_pair_r<real>(R, G.twd + 32 * kPair); }
-    __syncthreads();
+    wave_fence();
     if (G.is_long) {
       float2 *p = z + G.zc;
       x[0] = p[0]; x[1] = p[20]; x[2] = p[40]; x[3] = p[60];
@@ -207,10 +213,15 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
       r2_bf<real>(x[0], x[2], n1); r2_bf<real>(x[1], x[3], n2);
       if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
     }
-    t0 = table_pair_r<real>(R, G.post_tab[0]); t1 = table_pair_r<real>(R, G.post_tab[1]);
-    t2 = table_pair_r<real>(R, G.post_tab[2]); t3 = table_pair_r<real>(R, G.post_tab[3]);
+    if (late) {
+      t0 = table_pair_r<real>(R, (int)late[256]); t1 = table_pair_r<real>(R, (int)late[320]);
+      t2 = table_pair_r<real>(R, (int)late[384]); t3 = table_pair_r<real>(R, (int)late[448]);
+    } else {
+      t0 = table_pair_r<real>(R, G.post_tab[0]); t1 = table_pair_r<real>(R, G.post_tab[1]);
+      t2 = table_pair_r<real>(R, G.post_tab[2]); t3 = table_pair_r<real>(R, G.post_tab[3]);
+    }
     if (band2_long) {
-      __syncthreads();
+      wave_fence();
       if (G.band2) {
         const float2 *p = z + G.zd;
         x[0] = p[0]; x[1] = p[80]; x[2] = p[40]; x[3] = p[120];
@@ -218,13 +229,14 @@ __device__ __forceinline__ void imdct_r4(const float *coef, float2 *z, float *mi
       }
     }
   } else { t0 = n0; t1 = n1; t2 = n2; t3 = n3; }
-  __syncthreads();                                          // `mid` is the memory of `z`: every point has been read by now
+  wave_fence();                                          // `mid` is the memory of `z`: every point has been read by now
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const pair t = j == 0 ? t0 : (j == 1 ? t1 : (j == 2 ? t2 : t3));
     const real rr = x[j].x, ii = x[j].y;
-    mid[G.ox[j]] = (float)(rr * t.x + ii * t.y);            // mdct.js:177-208
-    mid[G.oy[j]] = (float)(rr * t.y - ii * t.x);
+    const uint32_t oo = late ? late[64 * j] : ((uint32_t)G.ox[j] | ((uint32_t)G.oy[j] << 16));
+    mid[oo & 0xffffu] = (float)(rr * t.x + ii * t.y);       // mdct.js:177-208
+    mid[oo >> 16] = (float)(rr * t.y - ii * t.x);
   }
 }
 
@@ -246,11 +258,12 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
   if (lane < 3) S.words[53 + lane] = 0u;
   S.sf_tab[lane] = (real)C1_TABLES(L.tables)->scale_factors[lane];
   if (lane < 16) S.inv_tab[lane] = (real)C1_TABLES(L.tables)->inv_range[lane];
+  if (lane < 32) S.wtab[lane] = F32 ? (real)C1_TABLES(L.tables)->win32[lane] : (real)C1_TABLES(L.tables)->window[lane];
   // lane-only geometry, computed once per wave
   // A lane dequantizes the eight CONSECUTIVE slots 8 lane .. 8 lane + 7 (BFU-major order = bit-stream order = coefficient
   // order of a long band): one running bit cursor, one 64-bit window read per mantissa, two 16-byte stores.  They lie in at
   // most three BFUs b0, b0 + 1, b0 + 2: dq_geo = b0 | index of slot 8 lane inside b0 << 6 | mask of the slots past the first
-  // boundary << 11 | mask of the slots past the second << 19.
+  // boundary << 11 | mask of the slots past the second << 19 (| SPECS_PER_BFU[lane] << 27, for the bit offsets).
   uint32_t dq_geo;
   {
     const int s0 = 8 * lane0, b0 = bfu_of_slot(s0);
@@ -261,25 +274,38 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
       m1 |= (k >= 1 ? 1u : 0u) << m;
       m2 |= (k >= 2 ? 1u : 0u) << m;
     }
-    dq_geo = (uint32_t)b0 | ((uint32_t)(s0 - kBfuFirst[b0]) << 6) | (m1 << 11) | (m2 << 19);
+    dq_geo = (uint32_t)b0 | ((uint32_t)(s0 - kBfuFirst[b0]) << 6) | (m1 << 11) | (m2 << 19) | ((uint32_t)(lane0 < 52 ? kSpecs[lane0] : 0) << 27);
   }
   if (lane0 < 52) S.dshort[lane0] = (int16_t)((int)kStartShort[lane0] - (int)kBfuFirst[lane0]);
-  const int my_size = lane0 < 52 ? kSpecs[lane0] : 0;
-  const IMixGeometry IGL = imix_geometry<R>(lane0, FrameModes{0, 0, 0});   // all-long frames
+  IMixGeometry IGL = imix_geometry<R>(lane0, FrameModes{0, 0, 0});   // all-long frames
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    S.late[j][lane0] = (uint32_t)IGL.ox[j] | ((uint32_t)IGL.oy[j] << 16);
+    S.late[4 + j][lane0] = (uint32_t)IGL.post_tab[j];
+    IGL.ox[j] = IGL.oy[j] = IGL.post_tab[j] = 0;              // not carried through the loop
+  }
   const TablesRsrc RT = tables_rsrc(L.tables);
-  __syncthreads();
+  wave_fence();
 
   const int64_t f_end = (f0 + L.run_frames < L.frames) ? f0 + L.run_frames : L.frames;
-  for (int64_t f = f0 - 1; f < f_end; ++f) {
-    if (f < -(int64_t)L.halo_units) continue;
+  int64_t f_first = f0 - 1;                                  // the unit before the run rebuilds the state
+  if (f_first < -(int64_t)L.halo_units) f_first = f0;
+  // the unit's 53 dwords are requested one unit ahead (a lane's dword) and taken delivery of before the PCM stores of the
+  // unit in between are issued: loads and stores share one counter on this part, so a wait for a load behind a store is
+  // a wait for the store to reach memory (c1_k_spec.hip)
+  auto unit_word = [&](int64_t fr) -> uint32_t {
+    return reinterpret_cast<const uint32_t *>(L.units + (fr * L.channels + ch) * C1_UNIT_BYTES)[lane0 < 53 ? lane0 : 0];
+  };
+  uint32_t next_word = unit_word(f_first);
+  for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = f >= f0;
-    const int64_t unit = f * L.channels + ch;
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
 
     // ---------------- deserializeFrame (serialization.js:111-176) ----------------
-    if (lane < 53) S.words[lane] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(L.units + unit * C1_UNIT_BYTES)[lane]);
-    __syncthreads();
+    if (lane < 53) S.words[lane] = __builtin_bswap32(next_word);
+    next_word = unit_word(f + 1 < f_end ? f + 1 : f);
+    wave_fence();
     const uint32_t header = S.words[0] >> 16;
     const int m0 = 2 - (int)((header >> 14) & 3), m1 = 2 - (int)((header >> 12) & 3), m2 = 3 - (int)((header >> 10) & 3);
     const int n = bfu_amount((header >> 5) & 7);
@@ -288,14 +314,14 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
       wl = (int)get_bits_be(S.words, 16 + 4 * lane, 4);
       sfi = (int)get_bits_be(S.words, 16 + 4 * n + 6 * lane, 6);
     }
-    const int mybits = wl_bits(wl) * my_size;
+    const int mybits = wl_bits(wl) * (int)(dq_geo >> 27);            // SPECS_PER_BFU[lane] rides in the geometry word
     const int scan = wave_inclusive_scan(mybits);
     if (lane < 52) {
       S.desc[lane] = (uint32_t)wl_bits(wl) | ((uint32_t)sfi << 5) | ((uint32_t)(16 + 10 * n + scan - mybits) << 11);
       // SF * RN(1 / range) (see dq_step); a BFU with scale factor 0 dequantizes to zeros (quantization.js:66-68)
       S.step[lane] = sfi != 0 ? S.sf_tab[sfi] * S.inv_tab[wl_bits(wl) > 0 ? wl_bits(wl) - 1 : 0] : (real)0;
     }
-    __syncthreads();
+    wave_fence();
     // ---------------- dequantizationStage (decoder.js:52-98) ----------------
     const bool all_long = (m0 | m1 | m2) == 0;
     {
@@ -362,18 +388,18 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
         }
       }
     }
-    __syncthreads();
+    wave_fence();
 
     // ---------------- imdctStage (decoder.js:116-330) ----------------
     float *mid = S.u.m.zz.mid;
     if (all_long) {
-      imdct_r4<R>(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT);
-      __syncthreads();
+      imdct_r4<R>(S.cb.coef, S.u.m.zz.z, mid, IGL, true, true, T, RT, &S.late[0][0] + lane);
+      wave_fence();
       // overlap-add of the first 32 samples of every band (mdct.js:230-245 via decoder.js:203-232) ...
       if (lane < 32) {
         const bool lo = lane < 16;
         const int i = lo ? lane : 31 - lane;
-        const real wa = F32 ? (real)T->win32[i] : (real)T->window[i], wb = F32 ? (real)T->win32[31 - i] : (real)T->window[31 - i];   // w1 = W[i], w2 = W[31-i]
+        const real wa = S.wtab[i], wb = S.wtab[31 - i];   // w1 = W[i], w2 = W[31-i]
 #pragma unroll
         for (int b = 0; b < 3; b++) {
           const int off = b == 0 ? 0 : (b == 1 ? 128 : 256);
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
     FrameModes M{m0, m1, m2};
     const IMixGeometry IG = imix_geometry<R>(lane, M);
     imdct_r4<R>(S.cb.coef, S.u.m.zz.z, mid, IG, m0 == 0 || m1 == 0 || m2 == 0, m2 == 0, T, RT);
-    __syncthreads();
+    wave_fence();
     // overlap-add (mdct.js:230-245 via decoder.js:203-232 long / :262-300 short)
 #pragma unroll
     for (int m = 0; m < 8; m++) {
@@ -407,11 +433,11 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
         const float *prev = (q == 0) ? (S.tail + 16 * b) : (mid + off + 32 * (q - 1) + 16);
         const float *curr = mid + off + 32 * q;
         if (k < 16) {
-          const real w1 = F32 ? (real)T->win32[k] : (real)T->window[k], w2 = F32 ? (real)T->win32[31 - k] : (real)T->window[31 - k];
+          const real w1 = S.wtab[k], w2 = S.wtab[31 - k];
           v = (float)((real)prev[k] * w2 - (real)curr[15 - k] * w1);
         } else {
           const int i = 31 - k;
-          const real w1 = F32 ? (real)T->win32[i] : (real)T->window[i], w2 = F32 ? (real)T->win32[31 - i] : (real)T->window[31 - i];
+          const real w1 = S.wtab[i], w2 = S.wtab[31 - i];
           v = (float)((real)prev[i] * w1 + (real)curr[15 - i] * w2);
         }
       } else {
@@ -420,13 +446,13 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
       S.cb.band[g] = v;
     }
     }
-    __syncthreads();
+    wave_fence();
     if (lane < 48) {
       const int b = lane >> 4, k = lane & 15;
       const int off = b == 0 ? 0 : (b == 1 ? 128 : 256), Sb = b == 2 ? 256 : 128;
       S.tail[lane] = mid[off + Sb - 16 + k];
     }
-    __syncthreads();
+    wave_fence();
 
     // ---------------- qmfSynthesisStage (decoder.js:349-389) ----------------
     real *w2 = S.u.q2.w2, *w1 = S.u.q1.w1;
@@ -449,14 +475,14 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
         pair v2; v2.x = (real)(float)((real)0.5 * (l + h)); v2.y = (real)(float)((real)0.5 * (l - h));
         *reinterpret_cast<pair *>(&w2[pidx<2>(46 + 2 * i)]) = v2;
       }
-      __syncthreads();
+      wave_fence();
       if (lane < 39) S.dhi[lane] = keep;
     }
     {
       real s0[2], s1[2];
       qmf_synth_r<R, 2, 2>(w2, lane, T, s0, s1);
       if (lane < 46) S.d2[lane] = w2[pidx<2>(256 + lane)];
-      __syncthreads();                                    // w1 reuses the memory of w2 from here on
+      wave_fence();                                    // w1 reuses the memory of w2 from here on
       if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
       // stage 1 input: (stage-2 output, delayed high); stage-2 output pair of i: out[2i] = s1, out[2i+1] = s0
 #pragma unroll
@@ -471,18 +497,19 @@ __global__ __launch_bounds__(C1_WAVE, (std::is_same<R, float>::value ? 4 : 3)) v
         }
       }
     }
-    __syncthreads();
+    wave_fence();
     {
       real s0[4], s1[4];
       qmf_synth_r<R, 4, 3>(w1, lane, T, s0, s1);
       if (lane < 46) S.d1[lane] = w1[pidx<3>(512 + lane)];
+      asm volatile("" : "+v"(next_word));                 // the next unit has arrived: nothing waits on a load behind the stores below
       if (emit) {
         float4 *dst = reinterpret_cast<float4 *>(pcm + f * 512 + 8 * lane);
         dst[0] = make_float4((float)s1[0], (float)s0[0], (float)s1[1], (float)s0[1]);
         dst[1] = make_float4((float)s1[2], (float)s0[2], (float)s1[3], (float)s0[3]);
       }
     }
-    __syncthreads();
+    wave_fence();
   }
 }
 
