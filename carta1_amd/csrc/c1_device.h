@@ -508,7 +508,7 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
   // (the twiddles of rounds C and D take the registers the pre-twiddle pairs just left)
   const double2 wCa = table_pair(R, G.twc), wCb = table_pair(R, G.twc + 256), wCc = table_pair(R, G.twc + 512);
   const double2 wDa = table_pair(R, G.twd), wDb = table_pair(R, G.twd + 512);
-  __syncthreads();
+  wave_fence();
   // ---- round B: stages 4, 8 ----
   {
     float2 *p = z + G.zb;
@@ -520,7 +520,7 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
   }
   const double2 p0 = table_pair(R, G.post_tab[0]), p1 = table_pair(R, G.post_tab[1]);
   const double2 p2 = table_pair(R, G.post_tab[2]), p3 = table_pair(R, G.post_tab[3]);
-  __syncthreads();
+  wave_fence();
   // ---- round C: stages 16, 32 ----
   {
     float2 *p = z + G.zc;
@@ -530,7 +530,7 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
     r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
     if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
   }
-  __syncthreads();
+  wave_fence();
   // ---- round D: stage 64 of the 128-point transform ----
   if (G.band2) {
     const float2 *p = z + G.zd;
@@ -689,7 +689,7 @@ __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, flo
   }
   const double2 p0 = table_pair(R, G.post_tab[0]), p1 = table_pair(R, G.post_tab[1]);
   const double2 p2 = table_pair(R, G.post_tab[2]), p3 = table_pair(R, G.post_tab[3]);
-  __syncthreads();
+  wave_fence();
   {
     float2 *p = z + G.zb;
     const double2 wa = wBa, wb = wBb, wc = wBc;
@@ -699,7 +699,7 @@ __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, flo
     if (G.is_long) { p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3]; }
   }
   if (any_long) {
-    __syncthreads();
+    wave_fence();
     if (G.is_long) {
       float2 *p = z + G.zc;
       const double2 wa = table_pair(R, G.twc), wb = table_pair(R, G.twc + 256), wc = table_pair(R, G.twc + 512);
@@ -709,7 +709,7 @@ __device__ __forceinline__ void mdct_mixed_r4(const float *stage, float2 *z, flo
       if (G.band2) { p[0] = x[0]; p[20] = x[1]; p[40] = x[2]; p[60] = x[3]; }
     }
     if (band2_long) {
-      __syncthreads();
+      wave_fence();
       if (G.band2) {
         const float2 *p = z + G.zd;
         const double2 wa = table_pair(R, G.twd), wb = table_pair(R, G.twd + 512);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   const SfLong SFM = sf_geometry(lane0, O->modes[0], O->modes[1], O->modes[2]);     // used when !ALL_LONG
   const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
   const TablesRsrc RT = tables_rsrc(L.tables);
-  __syncthreads();
+  wave_fence();
 
   const int64_t f_end = (f0 + run_frames < L.frames) ? f0 + run_frames : L.frames;
   constexpr int kWarm = 1;                         // one frame of history rebuilds the state
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 256)]) = make_double2((double)b.x, (double)b.y);
       *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
     }
-    __syncthreads();
+    wave_fence();
     {
       double ev[4], od[4];
       if constexpr (ALL_LONG) __builtin_amdgcn_s_setprio(3);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 4 * lane)]) = make_double2((double)lo[0], (double)lo[1]);
       *reinterpret_cast<double2 *>(&w2[pidx<2>(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
     }
-    __syncthreads();
+    wave_fence();
     R4Early EARLY;
     if constexpr (ALL_LONG) EARLY = r4_early(G4, RT);          // in flight during the second QMF stage
     {
@@ -151,11 +151,11 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       *reinterpret_cast<float4 *>(&band_[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
       if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx<2>(256 + lane)];
     }
-    __syncthreads();
+    wave_fence();
     {
       float keep = 0.0f;
       if (lane < 39) keep = S.hbuf[256 + lane];
-      __syncthreads();
+      wave_fence();
       if (lane < 39) S.hbuf[lane] = keep;
     }
     if (emit && L.bands) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
         }
       }
       ov0 = nov0; ov1 = nov1; ov2 = nov2;
-      if (!emit) { __syncthreads(); continue; }
+      if (!emit) { wave_fence(); continue; }
       // zero regions and the body of every band (everything before the tail) straight into the MDCT inputs
       {
         const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -198,14 +198,14 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
         }
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
-      __syncthreads();
+      wave_fence();
       float *coef = S.u.m.a.c.coef;
       // Wave priorities: the QMF cores saturate VALU and LDS together (3), the MDCT rounds are chains of dependent
       // round trips that the other waves fill anyway (0), staging and output in between (1).  Measured: -4 %.
       __builtin_amdgcn_s_setprio(0);
       mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT, EARLY);
       __builtin_amdgcn_s_setprio(1);
-      __syncthreads();
+      wave_fence();
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
       const int64_t unit = f * L.channels + ch;
@@ -217,17 +217,17 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       }
       sf_long(coef, S.sfi, SFL, T);
       if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
-      __syncthreads();
+      wave_fence();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
       if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // exact coefficients: bounds of zero
-      __syncthreads();
+      wave_fence();
     } else {
       // ---------------- mdctStage with short blocks (encoder.js:170-349), fixed block modes ----------------
       const FrameModes M{O->modes[0], O->modes[1], O->modes[2]};
       float *coef = S.u.m.a.c.coef;
       if (emit) {
         mix_stage(band_, S.ovl, S.u.m.a.g.in, M, lane, RT);
-        __syncthreads();
+        wave_fence();
         mdct_mixed_r4(S.u.m.a.g.in, S.u.m.zz.z, coef, GM, M.m0 == 0 || M.m1 == 0 || M.m2 == 0, M.m2 == 0, T, RT);
       }
       // applyTailWindowing's overlap half (encoder.js:309-316): W[i] * last 32 raw samples of the band
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
         const int Sb = b == 2 ? 256 : 128, off = b == 0 ? 0 : (b == 1 ? 128 : 256);
         S.ovl[i] = f32(T->window[k] * (double)band_[off + Sb - 32 + k]);
       }
-      __syncthreads();
+      wave_fence();
       if (!emit) continue;
 
       // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
@@ -249,13 +249,13 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       }
       sf_long(coef, S.sfi, SFM, T);                       // same 12-read scheme, BFU starts of the fixed modes
       if (lane >= 60 && lane < 63) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60)] = lane == 60 ? (uint32_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0u;
-      __syncthreads();
+      wave_fence();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
       if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      __syncthreads();
+      wave_fence();
     }
   }
-  __syncthreads();
+  wave_fence();
   }
 }
 

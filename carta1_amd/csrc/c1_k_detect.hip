@@ -326,7 +326,7 @@ __device__ __forceinline__ void tfft_exact(const float *band, float2 *z, const T
 #pragma unroll
     for (int j = 0; j < 4; j++) dst[j] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
   }
-  __syncthreads();
+  wave_fence();
   {
     float2 *p = z + G.zb;                                    // stages 8, 16, 32 on the points p + 8j
 #pragma unroll
@@ -340,7 +340,7 @@ __device__ __forceinline__ void tfft_exact(const float *band, float2 *z, const T
   const double2 wDa = table_pair(RT, G.twd), wDb = table_pair(RT, G.twd + 512);
   const double2 wC0 = table_pair(RT, G.twc), wC1 = table_pair(RT, G.twc + G.twc_stride);
   const double2 wC2 = table_pair(RT, G.twc + 2 * G.twc_stride), wC3 = table_pair(RT, G.twc + 3 * G.twc_stride);
-  __syncthreads();
+  wave_fence();
   {
     // points g + S*t, t = 0..7.  Band 2 first runs stage 64 on them; then stage N/2 (64 for the 128-point
     // transforms, 128 for the 256-point one) pairs (t, t+4) and only its e-outputs, the bins g + S*t, are needed
@@ -357,7 +357,7 @@ __device__ __forceinline__ void tfft_exact(const float *band, float2 *z, const T
       mg[i] = f32(sqrt(r * r + im * im));
     }
   }
-  __syncthreads();                                           // the per-bin terms reuse the memory of the points
+  wave_fence();                                           // the per-bin terms reuse the memory of the points
 }
 
 // feature terms per bin, then the reference's 18 sequential sums (transient.js:92-189) -> feat[0..18), nv[3] as int32 behind
@@ -386,7 +386,7 @@ __device__ __forceinline__ void exact_sums(double (*term)[256], const TGeom &G, 
     }
     nv_all = lane == 0 ? n0 : (lane == 1 ? n1 : n2);
   }
-  __syncthreads();
+  wave_fence();
   if (lane < 18) {
     // 18 lanes each own one running sum (3 bands x {flux, energy, log, linear, low, high}), index ascending
     const int b = lane / 6, kind = lane - 6 * b;
@@ -474,7 +474,7 @@ __device__ __forceinline__ void tfft_spec(const float *band, float2 *zf, const T
 #pragma unroll
     for (int j = 0; j < 4; j++) dst[j] = make_float4(c[2 * j].x, c[2 * j].y, c[2 * j + 1].x, c[2 * j + 1].y);
   }
-  __syncthreads();
+  wave_fence();
   {
     v2f *p = z + G.zb;                                       // stages 8, 16, 32 on the points p + 8j
 #pragma unroll
@@ -488,7 +488,7 @@ __device__ __forceinline__ void tfft_spec(const float *band, float2 *zf, const T
   const v2f wDa = table_f2(RT, G.twd32), wDb = table_f2(RT, G.twd32 + 256);
   const v2f wC0 = table_f2(RT, G.twc32), wC1 = table_f2(RT, G.twc32 + G.twc32_stride);
   const v2f wC2 = table_f2(RT, G.twc32 + 2 * G.twc32_stride), wC3 = table_f2(RT, G.twc32 + 3 * G.twc32_stride);
-  __syncthreads();
+  wave_fence();
   {
     const v2f *p = z + G.zc;
 #pragma unroll
@@ -500,7 +500,7 @@ __device__ __forceinline__ void tfft_spec(const float *band, float2 *zf, const T
       mg[i] = __builtin_sqrtf(__builtin_fmaf(e.y, e.y, e.x * e.x));
     }
   }
-  __syncthreads();
+  wave_fence();
 }
 
 // the ten sums of c1_detect_bound.h for the lane's row; lane 16 r writes row r of the frame's record
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
   float pmag[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // magnitudes of the previous frame at this lane's four bins
   const TGeom G = tfft_geometry(lane0);
   const TablesRsrc RT = tables_rsrc(L.tables);
-  __syncthreads();
+  wave_fence();
 
   const int64_t f_end = (f0 + L.run_frames < L.frames) ? f0 + L.run_frames : L.frames;
   int64_t f_first = f0 - 2;                                  // frame -2 rebuilds the QMF delay lines, frame -1 the magnitudes
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
       *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 256)]) = make_double2((double)b.x, (double)b.y);
       *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
     }
-    __syncthreads();
+    wave_fence();
     {
       double ev[4], od[4];
       __builtin_amdgcn_s_setprio(3);   // wave priorities as in k_analysis_fast: QMF cores 3, transient FFT 0, the rest 1
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
       *reinterpret_cast<double2 *>(&w2[pidx<2>(46 + 4 * lane)]) = make_double2((double)lo[0], (double)lo[1]);
       *reinterpret_cast<double2 *>(&w2[pidx<2>(48 + 4 * lane)]) = make_double2((double)lo[2], (double)lo[3]);
     }
-    __syncthreads();
+    wave_fence();
     {
       double ev[2], od[2];
       if (own_block()) qmf_analysis_core<2, 2>(S.u.q2.w2, lane, T, ev, od); else { for (int d = 0; d < 2; d++) { ev[d] = S.u.q2.w2[lane + d]; od[d] = 1.0; } }
@@ -606,14 +606,14 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
       *reinterpret_cast<float4 *>(&S.band[256 + 4 * lane]) = *reinterpret_cast<const float4 *>(&S.hbuf[4 * lane]);
       if (lane < 46) S.d2[lane] = S.u.q2.w2[pidx<2>(256 + lane)];
     }
-    __syncthreads();
+    wave_fence();
     {
       float keep = 0.0f;
       if (lane < 39) keep = S.hbuf[256 + lane];
-      __syncthreads();
+      wave_fence();
       if (lane < 39) S.hbuf[lane] = keep;
     }
-    if (qmf_only) { __syncthreads(); continue; }
+    if (qmf_only) { wave_fence(); continue; }
     const int64_t slot = (f + 1) * L.channels + ch;
     if (emit) {
       float4 *dst = reinterpret_cast<float4 *>(bands_ws + (slot << 9));
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
 #pragma unroll
     for (int i = 0; i < 4; i++) pmag[i] = mg[i];
     __builtin_amdgcn_s_setprio(1);
-    __syncthreads();
+    wave_fence();
   }
 }
 
@@ -809,31 +809,31 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_detect_recheck(C1EncodeLaunch L,
       const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + ((slot - L.channels) << 9));
       reinterpret_cast<float4 *>(S.band)[lane] = p4[lane];
       reinterpret_cast<float4 *>(S.band)[64 + lane] = p4[64 + lane];
-      __syncthreads();
+      wave_fence();
       tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
       exact_sums(S.u.tt.term, G, lane, mg, pmag, S.feat_p);    // its flux sum is not used
 #pragma unroll
       for (int k = 0; k < 4; k++) pmag[k] = mg[k];
-      __syncthreads();
+      wave_fence();
     }
     {
       const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
       reinterpret_cast<float4 *>(S.band)[lane] = p4[lane];
       reinterpret_cast<float4 *>(S.band)[64 + lane] = p4[64 + lane];
-      __syncthreads();
+      wave_fence();
       tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
       exact_sums(S.u.tt.term, G, lane, mg, pmag, S.feat_c);
-      __syncthreads();
+      wave_fence();
     }
     if (lane < 3) S.mode[lane] = detect_band_mode(S.feat_c, have_prev ? S.feat_p : nullptr, lane, T->log1p10, L.opts->threshold, nullptr);
-    __syncthreads();
+    wave_fence();
     if (lane == 0) {
       const int mode_byte = S.mode[0] | (S.mode[1] << 2) | (S.mode[2] << 4);
       modes[unit] = (uint8_t)mode_byte;
       const int k = mode_byte == 0 ? 0 : 1;
       lists[4 + (int64_t)k * units + atomicAdd(&lists[k], 1u)] = (uint32_t)unit;
     }
-    __syncthreads();
+    wave_fence();
   }
 }
 
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
       o.z = f32(wt2 * (double)t.z); o.w = f32(wt3 * (double)t.w);
       reinterpret_cast<float4 *>(S.ovl)[lane] = o;
     }
-    __syncthreads();
+    wave_fence();
     const FrameModes M{mode_byte & 3, (mode_byte >> 2) & 3, (mode_byte >> 4) & 3};
     float *coef = S.a.c.coef;
     if constexpr (LONG) {
@@ -941,15 +941,15 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
         }
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
-      __syncthreads();
+      wave_fence();
       mdct_long_r4(in0, S.zz.z, coef, G4, T, RT, r4_early(G4, RT));
-      __syncthreads();
+      wave_fence();
     } else {
       const MixGeometry GM = mix_geometry(lane, M);
       mix_stage(S.band, S.ovl, S.a.g.in, M, lane, RT);
-      __syncthreads();
+      wave_fence();
       mdct_mixed_r4(S.a.g.in, S.zz.z, coef, GM, M.m0 == 0 || M.m1 == 0 || M.m2 == 0, M.m2 == 0, T, RT);
-      __syncthreads();
+      wave_fence();
     }
     // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
     {
@@ -972,9 +972,9 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
         S.sfi[lane] = lane == 52 ? (uint8_t)mode_byte : 0;
       }
     }
-    __syncthreads();
+    wave_fence();
     if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit_now * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-    __syncthreads();
+    wave_fence();
   }
 }
 
