@@ -454,7 +454,12 @@ __device__ __forceinline__ void tfft_spec(const float *band, float2 *zf, const T
     const float amax = __uint_as_float(am);
     // squares of samples below 2^-63 underflow: below 2^-40 take sqrt(n) max|x| instead of the rounded sum
     const float w_up = amax < 9.094947e-13f ? 16.0f * amax : __builtin_sqrtf(ss) * 1.00001f;
-    delta = am == 0u ? 0.0f : __builtin_fmaf(T->det_ck[G.band], w_up, T->det_eabs) * 1.000001f;
+    // three scalar reads and a select, not a lane-varying load (a cache round trip waited for on the spot); the asm keeps the
+    // compiler from folding the select back into one
+    float ck0 = T->det_ck[0], ck1 = T->det_ck[1], ck2 = T->det_ck[2];
+    asm volatile("" : "+s"(ck0), "+s"(ck1), "+s"(ck2));
+    const float ck = G.band == 0 ? ck0 : (G.band == 1 ? ck1 : ck2);
+    delta = am == 0u ? 0.0f : __builtin_fmaf(ck, w_up, T->det_eabs) * 1.000001f;
   }
   // ---- round A: stages 1, 2, 4 of a real sequence; the rotations by -i are exact ----
   v2f c[8];
@@ -557,6 +562,8 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
   {
     const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
+    // delivered before the loop: a load still pending at the loop's entry makes the compiler wait inside the loop, every frame
+    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
   }
   for (int64_t f = f_first; f < f_end; ++f) {
     // frame -1 of the whole batch is emitted too (slot row 0): frame 0 needs its features and its band tails
@@ -568,10 +575,6 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
     // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
     {
       const float4 a = pre_a, b = pre_b;
-      if (f + 1 < f_end) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
-        pre_a = p4[lane]; pre_b = p4[64 + lane];
-      }
       double *w1 = S.u.q1.w1;
       if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
       const int e0 = 46 + 4 * lane;
@@ -581,6 +584,12 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
       *reinterpret_cast<double2 *>(&w1[pidx<3>(e0 + 258)]) = make_double2((double)b.z, (double)b.w);
     }
     wave_fence();
+    {
+      // the next frame's PCM (the last frame asks for itself again: under a condition the loaded values are copied into the
+      // loop-carried registers behind the load, i.e. waited for on the spot)
+      const float4 *p4 = reinterpret_cast<const float4 *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
+      pre_a = p4[lane]; pre_b = p4[64 + lane];
+    }
     {
       double ev[4], od[4];
       __builtin_amdgcn_s_setprio(3);   // wave priorities as in k_analysis_fast: QMF cores 3, transient FFT 0, the rest 1
@@ -613,14 +622,23 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
       wave_fence();
       if (lane < 39) S.hbuf[lane] = keep;
     }
+    // The next frame's PCM, requested before the first QMF stage, is taken delivery of here -- at a point every path to the top
+    // of the loop passes, and before any store of this frame is issued: a load still pending on ONE path makes the compiler wait
+    // at the top of the loop on ALL of them, and there the wait would sit right behind the frame's stores (loads and stores
+    // share one in-order counter on this part, vmcnt)
+    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
     if (qmf_only) { wave_fence(); continue; }
     const int64_t slot = (f + 1) * L.channels + ch;
-    if (emit) {
-      float4 *dst = reinterpret_cast<float4 *>(bands_ws + (slot << 9));
-      const float4 *src = reinterpret_cast<const float4 *>(S.band);
-      dst[lane] = src[lane];
-      dst[64 + lane] = src[64 + lane];
-    }
+    // Every store of the frame (bands, feature record) comes LAST: a wait for a load issued behind a store -- the table
+    // values of the transient FFT -- would be a wait for that store to reach memory.
+    auto store_bands = [&]() {
+      if (emit) {
+        float4 *dst = reinterpret_cast<float4 *>(bands_ws + (slot << 9));
+        const float4 *src = reinterpret_cast<const float4 *>(S.band);
+        dst[lane] = src[lane];
+        dst[64 + lane] = src[64 + lane];
+      }
+    };
 
     float mg[4];
     if constexpr (SPEC) {
@@ -632,8 +650,10 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
         for (int i = 0; i < 4; i++) L.mags[((f * L.channels + ch) << 8) + G.mag + i * G.S] = mg[i];
         if (L.mag_bounds && G.g == 0) L.mag_bounds[(f * L.channels + ch) * 3 + G.band] = delta;
       }
+      store_bands();
       if (emit) spec_sums(G, lane, mg, pmag, delta, reinterpret_cast<float *>(feat_ws + slot * kFeatureDoubles));
     } else {
+      store_bands();
       tfft_exact(S.band, S.u.t.z, G, T, RT, mg);
       if (L.mags && f >= f0) {                                   // stage tap: performFFT's magnitudes (transient.js:17-35)
 #pragma unroll
