@@ -900,29 +900,39 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   if (i >= count) return;
   float4 pre_a, pre_b, pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   int pre_mode = 0;
+  bool pre_have = false;                                     // wave-uniform: the fetched unit has a previous frame in the workspace
   auto fetch = [&](int64_t u) {
     const int64_t slot = u + L.channels;
     const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
-    const bool have_prev = ((L.channels == 2 ? u >> 1 : u) - 1 >= -(int64_t)L.halo_frames);
-    pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (have_prev && lane0 < 24) pre_t = *reinterpret_cast<const float4 *>(bands_ws + ((slot - L.channels) << 9) + tail_src);
+    pre_have = ((L.channels == 2 ? u >> 1 : u) - 1 >= -(int64_t)L.halo_frames);
+    // the tails are loaded unconditionally (from the unit's own slot where there is no previous frame; every lane: tail_src
+    // stays inside the slot) and masked when they are used: a load under a condition is waited for where it is issued
+    pre_t = *reinterpret_cast<const float4 *>(bands_ws + ((pre_have ? slot - L.channels : slot) << 9) + tail_src);
     if (!LONG) pre_mode = modes[u];
   };
-  int64_t unit = list[i];
-  int64_t unit_next = i + gridDim.x < count ? list[i + gridDim.x] : 0;
+  // The samples of the NEXT unit are requested while this one is transformed, unconditionally (past the end of the list the
+  // last unit is fetched again: under a condition the loaded values are copied into the loop-carried registers right behind
+  // the loads, i.e. waited for on the spot), and taken delivery of before this unit's stores are issued: loads and stores
+  // share one in-order counter on this part (vmcnt), so a wait for a load behind a store is a wait for the store as well.
+  auto listed = [&](uint32_t k) -> int64_t { return (int64_t)list[k < count ? k : count - 1]; };
+  auto deliver = [&]() {
+    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+    asm volatile("" : "+v"(pre_t.x), "+v"(pre_t.y), "+v"(pre_t.z), "+v"(pre_t.w), "+v"(pre_mode));
+  };
+  int64_t unit = listed(i);
+  int64_t unit_next = listed(i + gridDim.x);
   fetch(unit);
+  deliver();
   for (; i < count; i += gridDim.x) {
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
-    const float4 a = pre_a, b = pre_b, t = pre_t;
+    const float4 a = pre_a, b = pre_b, t = (pre_have && lane < 24) ? pre_t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int mode_byte = LONG ? 0 : __builtin_amdgcn_readfirstlane(pre_mode);
     const int64_t unit_now = unit;
-    if (i + gridDim.x < count) {
-      unit = unit_next;
-      fetch(unit);
-      if (i + 2 * gridDim.x < count) unit_next = list[i + 2 * gridDim.x];
-    }
+    unit = unit_next;
+    fetch(unit);
+    unit_next = listed(i + 2 * gridDim.x);
     reinterpret_cast<float4 *>(S.band)[lane] = a;
     reinterpret_cast<float4 *>(S.band)[64 + lane] = b;
     if (lane < 24) {
@@ -972,6 +982,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
       wave_fence();
     }
     // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+    deliver();
     {
       float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit_now << 9));
       const float4 *src = reinterpret_cast<const float4 *>(coef);
