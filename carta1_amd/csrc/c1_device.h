@@ -470,7 +470,16 @@ __device__ __forceinline__ R4Early r4_early(const R4Geometry &G, TablesRsrc R) {
 }
 // in: 1024 floats (in0 | in1 | in2, zero padded long-block inputs); z: 320 slots; coef: 512 floats (may share
 // memory with `in`: the inputs are dead once round A has read them)
-__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R, const R4Early &E) {
+// late: when not null, the lane's values of the END of the transform read back from LDS instead of being carried in registers
+// through the caller's frame loop: late[64 j] = cx[j] | cy[j] << 9 | (post-twiddle pair index of point j) << 18 (j = 0..3; the
+// pointer is the lane's; r4_late_word).  In k_analysis_fast they pushed a dozen values to scratch, and a scratch reload is a
+// vector-memory load: it waits on the counter the PCM prefetch and the frame's stores share.
+__device__ __forceinline__ uint32_t r4_late_word(const R4Geometry &G, int j) {
+  const int tab_base = G.band2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256);
+  return (uint32_t)G.cx[j] | ((uint32_t)G.cy[j] << 9) | ((uint32_t)((G.post_tab[j] - tab_base) >> 4) << 18);
+}
+__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R, const R4Early &E,
+                                             const uint32_t *late = nullptr) {
   float2 x[4];
   // the lane-varying table values of the frame are requested up front: the loads are in flight while round A
   // reads its inputs, instead of one cache round trip in front of every round
@@ -518,8 +527,15 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
     r2_butterfly(x[0], x[2], wb); r2_butterfly(x[1], x[3], wc);
     p[0] = x[0]; p[4] = x[1]; p[8] = x[2]; p[12] = x[3];
   }
-  const double2 p0 = table_pair(R, G.post_tab[0]), p1 = table_pair(R, G.post_tab[1]);
-  const double2 p2 = table_pair(R, G.post_tab[2]), p3 = table_pair(R, G.post_tab[3]);
+  uint32_t lw[4] = {0u, 0u, 0u, 0u};
+  int pt[4] = {G.post_tab[0], G.post_tab[1], G.post_tab[2], G.post_tab[3]};
+  if (late) {
+    const int tab_base = G.band2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { lw[j] = late[64 * j]; pt[j] = tab_base + (int)(lw[j] >> 18) * 16; }
+  }
+  const double2 p0 = table_pair(R, pt[0]), p1 = table_pair(R, pt[1]);
+  const double2 p2 = table_pair(R, pt[2]), p3 = table_pair(R, pt[3]);
   wave_fence();
   // ---- round C: stages 16, 32 ----
   {
@@ -543,8 +559,9 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
   for (int j = 0; j < 4; j++) {
     const double2 t = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
     const double rr = x[j].x, ii = x[j].y;
-    coef[G.cx[j]] = f32(-rr * t.x - ii * t.y);
-    coef[G.cy[j]] = f32(-rr * t.y + ii * t.x);
+    const uint32_t cc = late ? lw[j] : ((uint32_t)G.cx[j] | ((uint32_t)G.cy[j] << 9));
+    coef[cc & 511u] = f32(-rr * t.x - ii * t.y);
+    coef[(cc >> 9) & 511u] = f32(-rr * t.y + ii * t.x);
   }
 }
 

@@ -13,8 +13,11 @@ namespace {
 // their count: MDCT inputs in LDS buffers, FFT on interleaved (re,im) pairs with lane-only geometry
 // computed once per wave, bank-conflict-free layouts (tools/lds_model.py), no per-element mode logic.
 struct alignas(16) LongLds {
-  double d1[46];                 // stage-1 QMF delay line
-  double d2[46];                 // stage-2 QMF delay line
+  float d1[46];                  // stage-1 QMF delay line (binary32 samples; widened when they enter the work buffer)
+  float d2[46];                  // stage-2 QMF delay line
+  uint32_t late[4][64];          // mdct_long_r4's end-of-transform values per lane (r4_late_word)
+  uint32_t sfw[64];              // the lane's scale-factor scan: first coefficient | count << 9 | BFU << 13 | wide << 19 | store << 20
+  double win[32];                // WINDOW_SHORT (the tail windowing's lane-varying lookups: a global load each, waited for on the spot)
   alignas(16) float hbuf[296];   // delayed high band: [0,39) tail of the previous frame, [39,295) this frame
   alignas(4) uint8_t sfi[64];
   // scratch with disjoint lifetimes inside one frame (10 KiB per wave in total: 16 waves per CU)
@@ -85,8 +88,17 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   }
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
   // lane-only geometry of the long-block MDCT core, computed once (everything else is re-derived per frame)
-  const R4Geometry G4 = r4_geometry(lane0);
+  R4Geometry G4 = r4_geometry(lane0);
   const SfLong SFL = sf_long_geometry(lane0);
+  if constexpr (ALL_LONG) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      S.late[j][lane0] = r4_late_word(G4, j);
+      G4.cx[j] = G4.cy[j] = G4.post_tab[j] = 0;             // not carried through the loop
+    }
+    S.sfw[lane0] = (uint32_t)SFL.src | ((uint32_t)SFL.b << 13) | (SFL.wide ? 1u << 19 : 0u) | (SFL.store ? 1u << 20 : 0u);
+    if (lane0 < 32) S.win[lane0] = C1_TABLES(L.tables)->window[lane0];
+  }
   const SfLong SFM = sf_geometry(lane0, O->modes[0], O->modes[1], O->modes[2]);     // used when !ALL_LONG
   const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
   const TablesRsrc RT = tables_rsrc(L.tables);
@@ -98,10 +110,19 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;   // before the stream start the zero state stays
   if (f_first > f0) f_first = f0;
   // the PCM of the next frame is fetched while the current one is processed (two 16-byte loads per lane)
+  // The next frame's PCM is requested a frame ahead, unconditionally (the last frame of a run asks for itself again: under a
+  // condition the loaded values are copied into the loop-carried registers right behind the load, i.e. waited for on the
+  // spot), and taken delivery of at a point every path through the frame passes, BEFORE the frame's stores are issued: loads
+  // and stores share one in-order counter on this part (vmcnt), so a wait for a load behind a store is a wait for the store
+  // to reach memory as well (c1_k_spec.hip, tools/isa_waits.py).
   float4 pre_a, pre_b;
+  auto deliver = [&]() {
+    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+  };
   {
     const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
+    deliver();
   }
   for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = (f >= f0);
@@ -111,8 +132,8 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
     // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
     {
       const float4 a = pre_a, b = pre_b;
-      if (f + 1 < f_end) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + (f + 1) * 512);
+      {
+        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
         pre_a = p4[lane]; pre_b = p4[64 + lane];
       }
       double *w1 = S.u.q1.w1;
@@ -158,6 +179,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       wave_fence();
       if (lane < 39) S.hbuf[lane] = keep;
     }
+    deliver();
     if (emit && L.bands) {
       float4 *dst = reinterpret_cast<float4 *>(L.bands + ((f * L.channels + ch) << 9));
       const float4 *src = reinterpret_cast<const float4 *>(band_);
@@ -171,7 +193,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       float *in0 = S.u.m.a.i.in0, *in1 = S.u.m.a.i.in1, *in2 = S.u.m.a.i.in2;
       float nov0 = 0.0f, nov1 = 0.0f, nov2 = 0.0f;
       if (lane < 32) {
-        const double w_lo = T->window[lane], w_hi = T->window[31 - lane];
+        const double w_lo = S.win[lane], w_hi = S.win[31 - lane];
         const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
         nov0 = f32(w_lo * x0); nov1 = f32(w_lo * x1); nov2 = f32(w_lo * x2);
         if (emit) {
@@ -203,20 +225,28 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       // Wave priorities: the QMF cores saturate VALU and LDS together (3), the MDCT rounds are chains of dependent
       // round trips that the other waves fill anyway (0), staging and output in between (1).  Measured: -4 %.
       __builtin_amdgcn_s_setprio(0);
-      mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT, EARLY);
+      mdct_long_r4(in0, S.u.zp.z, coef, G4, T, RT, EARLY, &S.late[0][0] + lane);
       __builtin_amdgcn_s_setprio(1);
       wave_fence();
 
-      // ---------------- coefficients out + scale-factor indices (bitallocation.js:80-90) ----------------
+      // ---------------- scale-factor indices (bitallocation.js:80-90), then every store of the frame ----------------
       const int64_t unit = f * L.channels + ch;
+      {
+        // the scan of sf_long from three 16-byte reads (sf_scan_long_groups), its geometry read back from LDS
+        const uint32_t sw = S.sfw[lane];
+        const float4 *grp = reinterpret_cast<const float4 *>(coef + (sw & 0x1fcu));
+        float mx = sf_scan_long_groups(grp[0], grp[1], grp[2]);
+        const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false));
+        mx = fmaxf(mx, ((sw >> 19) & 1u) ? other : 0.0f);
+        const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+        if ((sw >> 20) & 1u) S.sfi[(sw >> 13) & 63u] = (uint8_t)sfi;
+      }
       {
         float4 *dst = reinterpret_cast<float4 *>(L.coefs + (unit << 9));
         const float4 *src = reinterpret_cast<const float4 *>(coef);
         dst[lane] = src[lane];
         dst[64 + lane] = src[64 + lane];
       }
-      sf_long(coef, S.sfi, SFL, T);
-      if (!ALL_LONG && lane == 63) S.sfi[52] = 0;   // modes byte: this frame is all long
       wave_fence();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
       if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // exact coefficients: bounds of zero
@@ -280,4 +310,4 @@ void c1k_launch_analysis_long(const C1EncodeLaunch &L0, hipStream_t stream) {
   const int64_t blocks = L.unit_list ? std::min<int64_t>(L.frames * L.channels, 256 * 16) : runs * L.channels;
   hipLaunchKernelGGL((k_analysis_fast<true>), dim3((unsigned)blocks), dim3(C1_WAVE), 0, stream, L);
 }
-static_assert(sizeof(LongLds) <= 8192, "all-long analysis: 20 waves per CU need <= 8 KiB of LDS per wave");
+static_assert(sizeof(LongLds) <= 10240, "all-long analysis: 16 waves per CU (4 per SIMD, 128 registers) need <= 10 KiB of LDS per wave");
