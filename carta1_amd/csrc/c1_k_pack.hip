@@ -59,7 +59,10 @@ __device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, 
   const uint32_t *side = reinterpret_cast<const uint32_t *>(L.side + unit * kSideBytes);
   PackHeader h;
   h.al_wl = al[lane >> 3];
-  h.al7 = al[7];
+  // wave-uniform (amount index, fallback flag): a SCALAR load.  As a vector load it was converted to a scalar with
+  // v_readfirstlane right behind the load -- a wait, at the top of every unit, for a load just issued and, the counter being
+  // in order, for the previous unit's store before it (tools/isa_waits.py)
+  h.al7 = *reinterpret_cast<const __attribute__((address_space(4))) uint32_t *>(reinterpret_cast<uintptr_t>(al + 7));
   h.sd_sf = side[lane >> 2];
   h.sd_q = side[lane & 15];
   h.al_a = al[(lane + 7) & 7];
