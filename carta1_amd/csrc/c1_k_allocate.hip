@@ -174,12 +174,16 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
     const uint64_t word = b < 16 ? res0 : (b < 32 ? res1 : (b < 48 ? res2 : res3));
     const int wl = (int)((word >> ((b & 15) * 4)) & 15);
     const int size = kSpecs[b];
+    // the table value is loaded whatever s is (index 0 is a valid entry) and masked afterwards: a lane-varying table read is
+    // a cache round trip, and under a condition each of the 52 is waited for where it is issued, one after the other;
+    // unconditional, the compiler requests them in batches (tools/isa_waits.py)
+    const double bs = biased[s];
     if (b >= n || wl == 0) {
       // zeroBitDistortions[b] = Float32(biasedSF * 2 * size), 0 when sfi == 0 (:76,87-89)
-      total += s != 0 ? (double)f32(biased[s] * 2.0 * (double)size) : 0.0;
+      total += s != 0 ? (double)f32(bs * 2.0 * (double)size) : 0.0;
     } else if (s != 0) {
       const double ip2 = __hiloint2double((1023 - wl_bits(wl)) << 20, 0);   // INV_POWER_OF_TWO[bits] = 2^-bits
-      total += biased[s] * ip2 * (double)size;
+      total += bs * ip2 * (double)size;
     }
   }
 }
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
 #pragma unroll
     for (int b = 48; b < 52; b++) {
       const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
-      t6f += s != 0 ? (float)biased[s] * (2.0f * (float)kSpecs[b]) : 0.0f;
+      const float bs = (float)biased[s];
+      t6f += s != 0 ? bs * (2.0f * (float)kSpecs[b]) : 0.0f;
     }
     const bool mine = n_coef > 0.0f && t6f < 0.35f * t_est && !getenv_no_tonal(O);
     // one decision per wave (the majority's): a heap loop runs as long as any lane of the wave needs it, so skipping
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_alloc_first(C1EncodeLaunch L) {
 #pragma unroll
     for (int b = 20; b < 52; b++) {
       const int s = (sf[b >> 2] >> ((b & 3) * 8)) & 63;
-      const double z = s != 0 ? (double)f32(biased[s] * 2.0 * (double)kSpecs[b]) : 0.0;
+      const double bs = biased[s];                                  // unconditional: see run_candidate
+      const double z = s != 0 ? (double)f32(bs * 2.0 * (double)kSpecs[b]) : 0.0;
       t0 += z;
       if (b >= 28) t1 += z;
       if (b >= 32) t2 += z;
