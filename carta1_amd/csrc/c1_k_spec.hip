@@ -39,14 +39,25 @@ struct alignas(16) SpecLds {
   alignas(16) float d1[48];          // stage-1 delay line (46)
   alignas(16) float d2[48];          // stage-2 delay line (46)
   alignas(16) float pre2[72];        // what the next frame's band-2 MDCT input starts with: windowed overlap (32), then the 39 delayed samples
-  alignas(16) float win[32];         // fl32(WINDOW_SHORT)
   alignas(4) uint8_t sfi[64];
   // lane-only values of the END of a frame (where the coefficients go, the post-twiddle pair, the scale-factor scan), read
   // back once per frame instead of being carried in registers through the whole loop: the register allocator spilled four
   // such values to scratch, and a scratch reload waits on the same counter as the coefficient stores issued just before it
   uint32_t geo[3][64];
 };
-static_assert(sizeof(SpecLds) <= 8192, "speculative analysis: 20 waves per CU");
+// The binary32 tables every frame reads with lane-varying indices -- WINDOW_SHORT, the MDCT (cos, sin) pairs, the radix-4
+// rounds' twiddles: C1DevTables::win32 .. r2d, contiguous, 2 784 bytes -- are kept in LDS, ONE copy per workgroup of
+// kSpecWaves waves (the waves share nothing else and never meet again after the copy).  Read through the cache they were
+// vector-memory loads: waits for them are waits on the counter the frame's stores share (in order), and under the write
+// traffic of this kernel a store takes long enough to reach memory that the first table wait of the NEXT frame still sat
+// behind it (measured with junk tables in LDS: -7 %).  With the tables in LDS the only vector-memory wait of a frame is the
+// delivery of the next frame's PCM, a whole frame behind the stores.
+constexpr int kSpecWaves = 4;
+constexpr int kSpecTabBase = (int)offsetof(C1DevTables, win32);
+constexpr int kSpecTabFloats = ((int)offsetof(C1DevTables, r2d) + (int)sizeof(((C1DevTables *)nullptr)->r2d) - kSpecTabBase) / 4;
+static_assert(offsetof(C1DevTables, pre32_64) > offsetof(C1DevTables, win32) && offsetof(C1DevTables, r2d) > offsetof(C1DevTables, r4c) &&
+              offsetof(C1DevTables, norm32) == offsetof(C1DevTables, r2d) + sizeof(((C1DevTables *)nullptr)->r2d), "win32 .. r2d are one contiguous block");
+static_assert(kSpecWaves * sizeof(SpecLds) + kSpecTabFloats * 4 <= 32768, "speculative analysis: 5 workgroups of 4 waves per CU");
 constexpr int kE2 = 0, kH2 = 288, kE0 = kR2, kH0 = kR2 + 160, kE1 = kR2 + 288, kH1 = kR2 + 448;
 
 __device__ __forceinline__ int w1_phys(int v) { return 12 * (v >> 3) + (v & 7); }
@@ -207,18 +218,32 @@ __device__ __forceinline__ uint32_t spread_block(uint32_t b, uint32_t n, int bit
 }
 
 template <bool SHORT>
-__global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) {
-  __shared__ SpecLds S;
-  const int lane0 = threadIdx.x;
+__global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1EncodeLaunch L) {
+  __shared__ SpecLds Sw[kSpecWaves];
+  __shared__ alignas(16) float tab[kSpecTabFloats];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  SpecLds &S = Sw[wave];
+  const int lane0 = threadIdx.x & 63;
   int lane = lane0;
-  const uint32_t slot = L.spread_bits > 0 ? spread_block(blockIdx.x, gridDim.x, L.spread_bits) : blockIdx.x;
+  {
+    const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.tables) + kSpecTabBase);
+    for (int i = threadIdx.x; i < kSpecTabFloats; i += C1_WAVE * kSpecWaves) tab[i] = src[i];
+  }
+  __syncthreads();                                          // the only time the waves of a workgroup meet
+  const float *win = tab;                                   // fl32(WINDOW_SHORT) = the first 32 floats
+  auto table_f2 = [&](int /*unused resource*/, int byte_offset) -> v2f {
+    return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(tab) + (byte_offset - kSpecTabBase));
+  };
+  const uint32_t n_slots = (uint32_t)((L.frames + L.run_frames - 1) / L.run_frames) * (uint32_t)L.channels;
+  const uint32_t vblock = blockIdx.x * kSpecWaves + (uint32_t)wave;
+  if (vblock >= n_slots) return;
+  const uint32_t slot = L.spread_bits > 0 ? spread_block(vblock, n_slots, L.spread_bits) : vblock;
   const int ch = (int)(slot % (uint32_t)L.channels);
   const int64_t f0 = (int64_t)(slot / (uint32_t)L.channels) * L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
   float *mem = S.mem;
 
   for (int i = lane; i < 48; i += 64) { S.d1[i] = 0.0f; S.d2[i] = 0.0f; }
-  if (lane < 32) S.win[lane] = C1_TABLES(L.tables)->win32[lane];
   float ov0a = 0.0f, ov0b = 0.0f, ov1a = 0.0f, ov1b = 0.0f;   // lanes 48..63: windowed overlap of bands 0, 1 for the next frame
   for (int i = lane; i < 72; i += 64) S.pre2[i] = 0.0f;
   if (lane < 16) reinterpret_cast<uint32_t *>(S.sfi)[lane] = 0u;
@@ -237,7 +262,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
   const int s_eb0 = (s_band == 0 ? kE0 : (s_band == 1 ? kE1 : kE2)) + 32 * s_blk;
   const int s_hb0 = (s_band == 0 ? kH0 : (s_band == 1 ? kH1 : kH2)) + 32 * s_blk;
   const int s_c0 = (s_band == 0 ? 0 : (s_band == 1 ? 128 : 256)) + 32 * s_blk + 2 * (s_g & 3);   // coefficient 2 i of the first final point
-  const TablesRsrc RT = tables_rsrc(L.tables);
+  constexpr int RT = 0;                         // table_f2(RT, offset): the tables are in LDS (above)
   float p_prev = 0.0f, q_prev = 0.0f;        // PCM / stage-1-low energies of the previous frame
   wave_fence();
 
@@ -249,6 +274,8 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
   {
     const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
+    // delivered before the loop: a load still pending at the loop's entry makes the compiler wait at the top of the loop, every frame
+    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
   }
   uint32_t deferred_from = 0xffffffffu;       // first unit of the part of this run that goes to the exact kernels (none)
   for (int64_t f = f_first; f < f_end; ++f) {
@@ -324,8 +351,8 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
           if (pos < 224) { if (emit) mem[kIn2 + 144 + pos] = x; }
           else if (pos < 256) {
             const int k = pos - 224;
-            S.pre2[k] = S.win[k] * x;
-            if (emit) mem[kIn2 + 144 + pos] = x * S.win[31 - k];
+            S.pre2[k] = win[k] * x;
+            if (emit) mem[kIn2 + 144 + pos] = x * win[31 - k];
           } else S.pre2[32 + pos - 256] = x;
         }
       }
@@ -336,8 +363,8 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
           if (lane < 32) mem[kE2 + lane] = S.pre2[lane];
           if (lane < 39) {
             const float x = S.pre2[32 + lane];
-            mem[kE2 + 32 + lane] = S.win[lane & 31] * x;
-            mem[kH2 + lane] = x * S.win[31 - (lane & 31)];
+            mem[kE2 + 32 + lane] = win[lane & 31] * x;
+            mem[kH2 + lane] = x * win[31 - (lane & 31)];
           }
         }
 #pragma unroll
@@ -345,8 +372,8 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
           const int pos = 39 + 4 * lane + d;
           const float x = hi[d];
           if (pos < 256) {
-            const float e = S.win[pos & 31] * x;
-            if (emit) { mem[kE2 + 32 + pos] = e; mem[kH2 + pos] = x * S.win[31 - (pos & 31)]; }
+            const float e = win[pos & 31] * x;
+            if (emit) { mem[kE2 + 32 + pos] = e; mem[kH2 + pos] = x * win[31 - (pos & 31)]; }
             if (pos >= 224) S.pre2[pos - 224] = e;
           } else S.pre2[32 + pos - 256] = x;
         }
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
         // the last 32 samples of bands 0, 1 (encoder.js:309-316): windowed into this frame's input, and, with the
         // mirrored window, kept in registers as the next frame's overlap, which these same lanes write then
         const int k = 2 * (lane - 48);
-        const float wl0 = S.win[k], wl1 = S.win[k + 1], wh0 = S.win[31 - k], wh1 = S.win[30 - k];
+        const float wl0 = win[k], wl1 = win[k + 1], wh0 = win[31 - k], wh1 = win[30 - k];
         if (emit) {
           *reinterpret_cast<float2 *>(&mem[kR2 + 48 + k]) = make_float2(ov0a, ov0b);
           *reinterpret_cast<float2 *>(&mem[kR2 + 256 + 48 + k]) = make_float2(ov1a, ov1b);
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
       }
       } else {
         const int k = (2 * lane) & 31;
-        const float wl0 = S.win[k], wl1 = S.win[k + 1], wh0 = S.win[31 - k], wh1 = S.win[30 - k];
+        const float wl0 = win[k], wl1 = win[k + 1], wh0 = win[31 - k], wh1 = win[30 - k];
         const float e00 = wl0 * lo[0], e01 = wl1 * lo[1], e10 = wl0 * hi[0], e11 = wl1 * hi[1];
         if (emit) {
           if (lane >= 48) {                                 // the overlap the previous frame left: E[0, 32)
@@ -407,7 +434,15 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     const float W = __builtin_amdgcn_sqrtf(P + p_prev), Lw = __builtin_amdgcn_sqrtf(Q + q_prev);
     p_prev = P; q_prev = Q;
     wave_fence();
-    if (!emit) continue;
+    // The next frame's PCM, requested during the first QMF stage, is taken delivery of HERE: before this frame's stores are
+    // issued -- loads and stores share one in-order counter on this part (vmcnt), so a wait for the PCM placed behind the
+    // stores, where the compiler would put it (the loop's back edge), is a wait for the stores to reach memory as well -- and
+    // at a point every path to the top of the loop passes: a load still pending on one path (the warm-up frame's `continue`)
+    // makes the compiler wait at the top of the loop on all of them.
+    if (!emit) {
+      asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+      continue;
+    }
 
     v2f x[4];
     float zrow;
@@ -571,10 +606,6 @@ __global__ __launch_bounds__(C1_WAVE, 5) void k_analysis_spec(C1EncodeLaunch L) 
     }
     // ---------------- the bound, coefficients out, scale-factor indices with their guard ----------------
     const int64_t unit = f * L.channels + ch;
-    // The next frame's PCM, requested during the first QMF stage, is taken delivery of HERE, before this frame's stores
-    // are issued: loads and stores share one counter on this part (vmcnt) and return out of order with each other, so a
-    // wait for the PCM placed behind the stores -- where the compiler puts it, at the loop's back edge -- is a wait for
-    // the stores to reach memory as well, once per frame.
     asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
     {
       // streaming stores (the packing kernel reads these 4 GB long after they have left the cache): -2 % of the kernel
@@ -703,11 +734,11 @@ void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, bool all_short, hipStrea
   static const int slots = c1k_wave_slots(k_analysis_spec<false>);
   C1EncodeLaunch L = L0;
   L.run_frames = c1k_pick_run(L.frames, L.channels, slots);
-  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames;
-  const dim3 grid((unsigned)(runs * L.channels)), block(C1_WAVE);
-  static const bool no_spread = getenv("C1_NO_SPREAD") != nullptr;     // experiments: workgroups in stream order
+  const int64_t runs = (L.frames + L.run_frames - 1) / L.run_frames, n_slots = runs * L.channels;
+  const dim3 grid((unsigned)((n_slots + kSpecWaves - 1) / kSpecWaves)), block(C1_WAVE * kSpecWaves);
+  static const bool no_spread = getenv("C1_NO_SPREAD") != nullptr;     // experiments: runs in stream order
   L.spread_bits = 0;
-  if (!no_spread) while ((1ll << L.spread_bits) < (int64_t)grid.x) L.spread_bits++;
+  if (!no_spread) while ((1ll << L.spread_bits) < n_slots) L.spread_bits++;
   if (all_short) hipLaunchKernelGGL((k_analysis_spec<true>), grid, block, 0, stream, L);
   else hipLaunchKernelGGL((k_analysis_spec<false>), grid, block, 0, stream, L);
 }
