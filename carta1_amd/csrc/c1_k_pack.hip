@@ -25,7 +25,9 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 constexpr int kPackWaves = 4;            // independent waves per workgroup, one sound unit at a time each
-constexpr int kPackBlocks = 2048;        // persistent grid: waves stride over the units
+// persistent grid: waves stride over the units.  Exactly the workgroups the device holds at once (pack_resident_blocks): with
+// more, the second round only partly fills the machine (2 048 workgroups at 1 280 resident: 1.085 ms per 2 M units; 2 560: 1.065;
+// 1 280: 1.024)
 
 constexpr int kRedoBatch = 32;           // one atomic on the list's counter per 32 listed units of a wave (every listed unit paying
                                          // its own serialises the whole kernel on that one address when most units are listed)
@@ -79,7 +81,7 @@ __device__ __forceinline__ PackHeader pack_load_header(const C1EncodeLaunch &L, 
 // with any doubtful mantissa, or whose scale-factor indices were doubtful, goes to the redo list and is encoded
 // again by the exact kernels.
 template <bool ALL_LONG, bool SPEC>
-__global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) void k_pack(C1EncodeLaunch L) {
+__global__ __launch_bounds__(C1_WAVE * kPackWaves, ALL_LONG ? 5 : 4) void k_pack(C1EncodeLaunch L) {
   __shared__ PackLds lds[kPackWaves];
   __shared__ typename std::conditional<SPEC, float, double>::type norm_s[64 * 16];   // quantRange / SCALE_FACTORS[sfi] (quantization.js:42-44)
   TablesPtr T = C1_TABLES(L.tables);
@@ -332,13 +334,24 @@ __global__ __launch_bounds__(C1_WAVE * kPackWaves, (ALL_LONG && !SPEC) ? 5 : 4) 
 
 }  // namespace
 
+template <class Kernel>
+static int pack_resident_blocks(Kernel kernel) {
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, C1_WAVE * kPackWaves, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  return per_cu * cus;
+}
+template <bool ALL_LONG, bool SPEC>
+static void launch_pack(const C1EncodeLaunch &L, hipStream_t stream) {
+  // the all-long speculative instantiation (5 waves per SIMD, the headline's): exactly the resident workgroups; the others
+  // (4 per SIMD) measured no better that way than with the two rounds they had
+  static const int resident = pack_resident_blocks(k_pack<ALL_LONG, SPEC>) * ((ALL_LONG && SPEC) ? 1 : 2);
+  const dim3 grid((unsigned)std::min<int64_t>(resident, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
+  hipLaunchKernelGGL((k_pack<ALL_LONG, SPEC>), grid, block, 0, stream, L);
+}
 void c1k_launch_pack(const C1EncodeLaunch &L, bool all_long, hipStream_t stream) {
-  const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
-  if (all_long) hipLaunchKernelGGL((k_pack<true, false>), grid, block, 0, stream, L);
-  else hipLaunchKernelGGL((k_pack<false, false>), grid, block, 0, stream, L);
+  if (all_long) launch_pack<true, false>(L, stream); else launch_pack<false, false>(L, stream);
 }
 void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t stream) {
-  const dim3 grid((unsigned)std::min<int64_t>(kPackBlocks, (L.frames * L.channels + kPackWaves - 1) / kPackWaves)), block(C1_WAVE * kPackWaves);
-  if (all_long) hipLaunchKernelGGL((k_pack<true, true>), grid, block, 0, stream, L);
-  else hipLaunchKernelGGL((k_pack<false, true>), grid, block, 0, stream, L);
+  if (all_long) launch_pack<true, true>(L, stream); else launch_pack<false, true>(L, stream);
 }
