@@ -247,7 +247,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
   float ov0a = 0.0f, ov0b = 0.0f, ov1a = 0.0f, ov1b = 0.0f;   // lanes 48..63: windowed overlap of bands 0, 1 for the next frame
   for (int i = lane; i < 72; i += 64) S.pre2[i] = 0.0f;
   if (lane < 16) reinterpret_cast<uint32_t *>(S.sfi)[lane] = 0u;
-  const SpecBase B0 = spec_base(lane0);
+  SpecBase B0 = spec_base(lane0);              // not const: passed through an opaque asm in place, once per frame (below)
   const SfLong SFL0 = SHORT ? sf_geometry(lane0, 2, 2, 3) : sf_long_geometry(lane0);
   if constexpr (!SHORT) {
     S.geo[0][lane0] = (uint32_t)(SFL0.src & ~3) | ((uint32_t)SFL0.b << 9) | (SFL0.wide ? 1u << 15 : 0u) | (SFL0.store ? 1u << 16 : 0u);
@@ -451,9 +451,10 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     // position 4g + j of the lane holds point k_j = r + q * bitrev2(j): j = 1 -> 2q, j = 2 -> q, j = 3 -> 3q
     // (the base values pass through an opaque asm once per frame: otherwise every address derived from them is
     // loop invariant, gets hoisted out of the frame loop and spilled)
-    SpecBase B = B0;
-    asm volatile("" : "+v"(B.ia0), "+v"(B.ic0), "+v"(B.q2), "+v"(B.ib), "+v"(B.id), "+v"(B.pt0));
-    asm volatile("" : "+v"(B.za), "+v"(B.zb), "+v"(B.zc), "+v"(B.zd), "+v"(B.g));
+    // (in place, on the loop-carried registers themselves: through a per-frame copy it cost 14 register moves a frame)
+    asm volatile("" : "+v"(B0.ia0), "+v"(B0.ic0), "+v"(B0.q2), "+v"(B0.ib), "+v"(B0.id), "+v"(B0.pt0));
+    asm volatile("" : "+v"(B0.za), "+v"(B0.zb), "+v"(B0.zc), "+v"(B0.zd), "+v"(B0.g));
+    const SpecBase &B = B0;
     {
       const int qb = 4 * B.q2;                               // bytes between the pre-twiddle pairs of points q apart
       const v2f t0 = table_f2(RT, B.pt0), t1 = table_f2(RT, B.pt0 + 2 * qb);
