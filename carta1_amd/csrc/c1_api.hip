@@ -510,7 +510,7 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
     HIP_TRY(hipMalloc(&ctx->d_cand[p], (size_t)units * kCandidateBytes));
     HIP_TRY(hipMalloc(&ctx->d_work[p], ((size_t)units * 8 + 4) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&ctx->d_eps[p], (size_t)units * kEpsFloats * sizeof(float)));
-    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units * 4 + kListHead) * sizeof(uint32_t)));   // counts, then four lists (bind_lists)
+    HIP_TRY(hipMalloc(&ctx->d_redo[p], ((size_t)units * 4 + kListHead + 64) * sizeof(uint32_t)));   // counts, then four lists (bind_lists) + slack for the masks of tiny batches
   }
   ctx->ws_units = units;
   return C1_OK;
@@ -703,6 +703,10 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
       L.eps = ctx->d_eps[p];
       bind_lists(ctx, p, &L);
       if (ctx->spec_mode == 1) { bind_defer(ctx, p, &L); L.spec_defer = ctx->spec_defer; }
+      // masks of the units with an open scale factor: behind the deferred runs' slots (one per run and channel, at most a
+      // quarter of the units: a run is at least 4 frames), two words per run; only with runs of at most 64 frames
+      if (c1k_pick_run(n, channels, 0) <= 64 && !getenv("C1_NO_SF_PREPASS"))
+        L.open_masks = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(ctx->d_redo[p] + kListHead + 3 * (size_t)ctx->ws_units + (size_t)ctx->ws_units / 4 + 4) + 7) & ~(uintptr_t)7);
       // this half of the workspace is free once the tail of the chunk that used it last is through
       if (overlap && ctx->tail_used[p]) HIP_TRY(hipStreamWaitEvent(sA, ctx->ev_tail[p], 0));
       HIP_TRY(hipMemsetAsync(ctx->d_redo[p], 0, kListHead * sizeof(uint32_t), sA));
@@ -718,6 +722,21 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
           D.list_runs = 1;
           D.defer_list = nullptr;
           if (all_long_modes) c1k_launch_analysis_long(D, sA); else c1k_launch_analysis(D, false, sA);
+        }
+        if (L.open_masks) {
+          // the units whose scale-factor guard stayed open (1.8 % of white noise) are re-analysed exactly HERE, in front of the
+          // allocation: it then sees the reference's indices the first time, and the redo behind the packing pass has no
+          // allocation chain of its own (five launches, one of them a lone heap run long: 0.13 ms per 2 M units)
+          C1EncodeLaunch X = L;
+          uint32_t *open_list = ctx->d_redo[p] + kListHead + 2 * (size_t)ctx->ws_units;   // the re-analysis list's space again (the
+          c1k_launch_open_compact(L, open_list, ctx->d_redo[p] + 5, sA);                  // deferred runs' list above is consumed)
+          X.unit_list = open_list;
+          X.unit_count = ctx->d_redo[p] + 5;
+          X.list_runs = 0;
+          X.list_zero_eps = 1;
+          X.defer_list = nullptr;
+          X.open_masks = nullptr;
+          if (all_long_modes) c1k_launch_analysis_long(X, sA); else c1k_launch_analysis(X, false, sA);
         }
       }
       { ScopedTiming t(ctx, K_ALLOCATE, sA); c1k_launch_allocate(L, sA); }

@@ -117,6 +117,11 @@ struct C1EncodeLaunch {
   // run, how many decisions of a unit the guards will leave open; past spec_defer it hands the rest of its run to the
   // exact kernels: defer_list[run * channels + channel] = first unit of the deferred part of that run, 0xffffffff = none
   uint32_t *defer_list;
+  // per run and channel, bit k set when the scale-factor guard left frame k of the run open (open_masks[run * channels +
+  // channel]; null: not collected).  Those units are re-analysed exactly BEFORE the allocation (c1_api.hip), so that the
+  // allocation sees the reference's indices the first time and the redo pass has no allocation chain of its own.
+  unsigned long long *open_masks;
+  int list_zero_eps;        // list mode of the analysis kernels: also write bounds of zero (the unit's coefficients are exact now)
   float spec_defer;         // threshold on the predicted number of open decisions per unit; +inf: never defer
   // list mode: when unit_list is non-null the kernels process units unit_list[0 .. *unit_count) instead of all
   const uint32_t *unit_list;
@@ -198,6 +203,8 @@ void c1k_launch_pack_spec(const C1EncodeLaunch &L, bool all_long, hipStream_t st
 void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream);
 // the speculative kernel's slot array (L.defer_list) -> dense list of deferred runs; counts[0] = entries, counts[1] = units covered
 void c1k_launch_defer_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *counts, hipStream_t stream);
+// open_masks -> a dense list of units (counts[0] = entries), for the exact pre-pass of the units with an open scale factor
+void c1k_launch_open_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *count, hipStream_t stream);
 void c1k_launch_decode(const C1DecodeLaunch &L, bool binary32, hipStream_t stream);   // binary32: opt-in, PCM within rounding noise of the reference
 // kind_mask: bit k = fill the 512-frame segments with (segment & 3) == k (15 = all)
 void c1k_launch_generate_white(const uint32_t *frame_states, int64_t frames, float *pcm, int kind_mask, double amp, hipStream_t stream);

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       }
       wave_fence();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-      if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // exact coefficients: bounds of zero
+      if ((L.list_runs || L.list_zero_eps) && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // exact coefficients: bounds of zero
       wave_fence();
     } else {
       // ---------------- mdctStage with short blocks (encoder.js:170-349), fixed block modes ----------------
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
       if (lane >= 60 && lane < 63) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60)] = lane == 60 ? (uint32_t)((M.m0 & 3) | ((M.m1 & 3) << 2) | ((M.m2 & 3) << 4)) : 0u;
       wave_fence();
       if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
-      if (L.list_runs && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if ((L.list_runs || L.list_zero_eps) && lane == 16) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       wave_fence();
     }
   }

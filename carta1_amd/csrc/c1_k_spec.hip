@@ -278,6 +278,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
   }
   uint32_t deferred_from = 0xffffffffu;       // first unit of the part of this run that goes to the exact kernels (none)
+  unsigned long long open_bits = 0ull;        // frames of this run whose scale-factor guard stayed open (wave-uniform)
   for (int64_t f = f_first; f < f_end; ++f) {
     const bool emit = (f >= f0);
     TablesPtr T = tables_for_this_frame(L.tables);
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     if (L.defer_list != nullptr && (((int)(f - f0)) & (kSpecCheckFrames - 1)) == 0) {
       if (spec_should_defer(S.sfi, lane, e0, e1, e2, L.opts, L.spec_defer)) { deferred_from = (uint32_t)unit; break; }
     }
+    if (any_unstable) open_bits |= 1ull << (int)((f - f0) & 63);        // (behind the hand-over test: a deferred frame is the exact kernels' already)
     if (lane < 16) reinterpret_cast<uint32_t *>(L.side + unit * kSideBytes)[lane] = reinterpret_cast<const uint32_t *>(S.sfi)[lane];
     if (lane == 0) *reinterpret_cast<float4 *>(L.eps + unit * kEpsFloats) = make_float4(e0, e1, e2, __int_as_float(any_unstable ? 1 : 0));
     wave_fence();
@@ -669,6 +671,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
   // one slot per run and channel, written by every workgroup (no list appends: tens of thousands of atomics on one counter
   // serialise at ~6-20 ns each, which cost 0.5 ms per 2 M units when a quarter of the runs were handed over)
   if (L.defer_list != nullptr && lane0 == 0) L.defer_list[slot] = deferred_from;
+  if (L.open_masks != nullptr && lane0 == 0) L.open_masks[slot] = open_bits;
 }
 
 // the slots of the deferred runs -> a dense list for the exact kernels (one atomic per wave; the order of the list is
@@ -699,6 +702,26 @@ __global__ __launch_bounds__(256) void k_defer_compact(const uint32_t *__restric
   if (on) list[at + __popcll(mask & ((1ull << lane) - 1ull))] = u;
 }
 
+// the open-scale-factor masks of the runs -> a dense list of units (one atomic per wave; the order of the list is free)
+__global__ __launch_bounds__(256) void k_open_compact(const unsigned long long *__restrict__ masks, uint32_t n_slots, uint32_t *__restrict__ list,
+                                                       uint32_t *__restrict__ count, int channels, int run_frames) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  unsigned long long m = i < n_slots ? masks[i] : 0ull;
+  const int mine = __popcll(m);
+  if (__builtin_amdgcn_ballot_w64(mine != 0) == 0) return;
+  const int scan = wave_inclusive_scan(mine);
+  const int lane = threadIdx.x & 63;
+  uint32_t at = 0;
+  if (lane == 63) at = atomicAdd(count, (uint32_t)scan);
+  at = (uint32_t)__builtin_amdgcn_readlane((int)at, 63) + (uint32_t)(scan - mine);
+  const uint32_t run = i / (uint32_t)channels, ch = i % (uint32_t)channels;
+  while (m != 0ull) {
+    const int k = __ffsll((long long)m) - 1;
+    m &= m - 1ull;
+    list[at++] = (run * (uint32_t)run_frames + (uint32_t)k) * (uint32_t)channels + ch;
+  }
+}
+
 // kind 0: a speculative call -- counts = the list head (redo, realloc, re-analysis, deferred runs, deferred units);
 // kind 1: exact coefficients quantized in binary32 -- counts[0] = units packed again;  kind 2: the speculative detector --
 // counts[0] = units rechecked.  Statistics only (c1_ctx_*_stats).
@@ -706,7 +729,7 @@ __global__ void k_spec_totals(unsigned long long *totals, unsigned long long uni
   if (kind == 0) {
     const unsigned long long deferred = counts[4];
     totals[0] += units - deferred;
-    totals[1] += counts[2];
+    totals[1] += counts[2] + counts[5];                     // re-analysed behind the packing pass + in front of the allocation (open scale factors)
     totals[2] += deferred;
     totals[3] += counts[0] - counts[2];
     totals[6] += deferred;
@@ -723,6 +746,12 @@ __global__ void k_spec_totals(unsigned long long *totals, unsigned long long uni
 
 void c1k_launch_spec_totals(unsigned long long *totals, uint64_t units, const uint32_t *counts, int kind, hipStream_t stream) {
   hipLaunchKernelGGL(k_spec_totals, dim3(1), dim3(1), 0, stream, totals, (unsigned long long)units, counts, kind);
+}
+void c1k_launch_open_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *count, hipStream_t stream) {
+  const int run = c1k_pick_run(L.frames, L.channels, 0);
+  const int64_t slots = (L.frames + run - 1) / run * L.channels;
+  hipLaunchKernelGGL(k_open_compact, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, (const unsigned long long *)L.open_masks, (uint32_t)slots, list, count,
+                     L.channels, run);
 }
 void c1k_launch_defer_compact(const C1EncodeLaunch &L, uint32_t *list, uint32_t *counts, hipStream_t stream) {
   const int run = c1k_pick_run(L.frames, L.channels, 0);
