@@ -723,7 +723,10 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
           D.defer_list = nullptr;
           if (all_long_modes) c1k_launch_analysis_long(D, sA); else c1k_launch_analysis(D, false, sA);
         }
-        if (L.open_masks) {
+      }
+      if (L.open_masks) {
+        ScopedTiming t(ctx, K_REDO, sA);                       // exact work on uncertain units: timed with the redo, wherever it runs
+        {
           // the units whose scale-factor guard stayed open (1.8 % of white noise) are re-analysed exactly HERE, in front of the
           // allocation: it then sees the reference's indices the first time, and the redo behind the packing pass has no
           // allocation chain of its own (five launches, one of them a lone heap run long: 0.13 ms per 2 M units)
@@ -759,10 +762,12 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
         R.unit_list = L.reana_list;
         R.unit_count = L.reana_count;
         if (all_long_modes) c1k_launch_analysis_long(R, sA); else c1k_launch_analysis(R, false, sA);
-        C1EncodeLaunch A = R;
-        A.unit_list = L.realloc_list;
-        A.unit_count = L.realloc_count;
-        c1k_launch_allocate(A, sA);
+        if (!L.open_masks) {                                   // with the pre-pass above no unit reaches the packing pass with an open scale factor
+          C1EncodeLaunch A = R;
+          A.unit_list = L.realloc_list;
+          A.unit_count = L.realloc_count;
+          c1k_launch_allocate(A, sA);
+        }
         R.unit_list = L.redo_list;
         R.unit_count = L.redo_count;
         c1k_launch_pack(R, all_long_modes, sA);
