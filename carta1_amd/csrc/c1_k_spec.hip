@@ -38,7 +38,8 @@ struct alignas(16) SpecLds {
   alignas(16) float mem[kMemFloats];
   alignas(16) float d1[48];          // stage-1 delay line (46)
   alignas(16) float d2[48];          // stage-2 delay line (46)
-  alignas(16) float pre2[72];        // what the next frame's band-2 MDCT input starts with: windowed overlap (32), then the 39 delayed samples
+  alignas(16) float pre2[76];        // what the next frame's band-2 MDCT input starts with: windowed overlap (32), then the 39 delayed samples;
+                                     // logical entry k lives at pre2[k + 1]: the tail lanes' four consecutive entries then start a 16-byte group
   alignas(4) uint8_t sfi[64];
   // lane-only values of the END of a frame (where the coefficients go, the post-twiddle pair, the scale-factor scan), read
   // back once per frame instead of being carried in registers through the whole loop: the register allocator spilled four
@@ -57,7 +58,7 @@ constexpr int kSpecTabBase = (int)offsetof(C1DevTables, win32);
 constexpr int kSpecTabFloats = ((int)offsetof(C1DevTables, r2d) + (int)sizeof(((C1DevTables *)nullptr)->r2d) - kSpecTabBase) / 4;
 static_assert(offsetof(C1DevTables, pre32_64) > offsetof(C1DevTables, win32) && offsetof(C1DevTables, r2d) > offsetof(C1DevTables, r4c) &&
               offsetof(C1DevTables, norm32) == offsetof(C1DevTables, r2d) + sizeof(((C1DevTables *)nullptr)->r2d), "win32 .. r2d are one contiguous block");
-static_assert(kSpecWaves * sizeof(SpecLds) + kSpecTabFloats * 4 <= 32768, "speculative analysis: 5 workgroups of 4 waves per CU");
+static_assert(kSpecWaves * sizeof(SpecLds) + kSpecTabFloats * 4 + 27 * 16 <= 32768, "speculative analysis: 5 workgroups of 4 waves per CU");
 constexpr int kE2 = 0, kH2 = 288, kE0 = kR2, kH0 = kR2 + 160, kE1 = kR2 + 288, kH1 = kR2 + 448;
 
 __device__ __forceinline__ int w1_phys(int v) { return 12 * (v >> 3) + (v & 7); }
@@ -221,6 +222,7 @@ template <bool SHORT>
 __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1EncodeLaunch L) {
   __shared__ SpecLds Sw[kSpecWaves];
   __shared__ alignas(16) float tab[kSpecTabFloats];
+  __shared__ alignas(16) float tail_w[27][4];               // band-2 tail weights of lanes 46..54 (this frame's input) and 46..63 (next frame's)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   SpecLds &S = Sw[wave];
   const int lane0 = threadIdx.x & 63;
@@ -228,6 +230,12 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
   {
     const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(L.tables) + kSpecTabBase);
     for (int i = threadIdx.x; i < kSpecTabFloats; i += C1_WAVE * kSpecWaves) tab[i] = src[i];
+    if (threadIdx.x < 27 * 4) {
+      const int idx = threadIdx.x >> 2, j = threadIdx.x & 3;
+      const bool input = idx < 9;                              // W[31 - k] x: positions 224..255 of this frame's input
+      const int k = 4 * (input ? idx : idx - 9) - 1 + j;      // k = position - 224 of element j of lane 46 + ...
+      tail_w[idx][j] = (k >= 0 && k < 32) ? src[input ? 31 - k : k] : 1.0f;     // src[0 .. 31] = fl32(WINDOW_SHORT)
+    }
   }
   __syncthreads();                                          // the only time the waves of a workgroup meet
   const float *win = tab;                                   // fl32(WINDOW_SHORT) = the first 32 floats
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
 
   for (int i = lane; i < 48; i += 64) { S.d1[i] = 0.0f; S.d2[i] = 0.0f; }
   float ov0a = 0.0f, ov0b = 0.0f, ov1a = 0.0f, ov1b = 0.0f;   // lanes 48..63: windowed overlap of bands 0, 1 for the next frame
-  for (int i = lane; i < 72; i += 64) S.pre2[i] = 0.0f;
+  for (int i = lane; i < 76; i += 64) S.pre2[i] = 0.0f;
   if (lane < 16) reinterpret_cast<uint32_t *>(S.sfi)[lane] = 0u;
   SpecBase B0 = spec_base(lane0);              // not const: passed through an opaque asm in place, once per frame (below)
   const SfLong SFL0 = SHORT ? sf_geometry(lane0, 2, 2, 3) : sf_long_geometry(lane0);
@@ -341,29 +349,32 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
       // band 2 = the high band behind its 39-sample delay (encoder.js:84-90): what the previous frame left (overlap,
       // 39 samples), then this frame's outputs; the last 32 samples of the band are windowed (encoder.js:309-316)
       if constexpr (!SHORT) {
-      if (emit) for (int i = lane; i < 71; i += 64) mem[kIn2 + 112 + i] = S.pre2[i];
+      if (emit) for (int i = lane; i < 71; i += 64) mem[kIn2 + 112 + i] = S.pre2[1 + i];
       if (lane <= 45) {                                     // positions 39 + 4 lane .. + 3 < 224: plain samples, one 16-byte group
         if (emit) *reinterpret_cast<float4 *>(&mem[kIn2 + 183 + 4 * lane]) = make_float4(hi[0], hi[1], hi[2], hi[3]);
       } else {
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          const int pos = 39 + 4 * lane + d;                // position in band 2 of this frame
-          const float x = hi[d];
-          if (pos < 224) { if (emit) mem[kIn2 + 144 + pos] = x; }
-          else if (pos < 256) {
-            const int k = pos - 224;
-            S.pre2[k] = win[k] * x;
-            if (emit) mem[kIn2 + 144 + pos] = x * win[31 - k];
-          } else S.pre2[32 + pos - 256] = x;
+        // Lanes 46..63 hold positions 223..294: the band's last 32 samples (224..255) are windowed both ways -- W[31 - k] x
+        // into this frame's input, W[k] x as the next frame's overlap (k = position - 224) -- and positions >= 256 are the
+        // next frame's delayed samples.  Branch-free: a lane's four weights of either kind come from a table (tail_w: 1
+        // outside the windowed stretch; the product with 1 is exact), its four results are one 16-byte store each.  (Per
+        // element, with three-way branches, this cost 5 % of the kernel.)
+        const float4 wl = *reinterpret_cast<const float4 *>(tail_w[9 + lane - 46]);
+        const v2f l01 = V2(hi[0], hi[1]) * V2(wl.x, wl.y), l23 = V2(hi[2], hi[3]) * V2(wl.z, wl.w);
+        *reinterpret_cast<float4 *>(&S.pre2[4 * (lane - 46)]) = make_float4(l01.x, l01.y, l23.x, l23.y);   // logical entries 4 (lane - 46) - 1 ..
+        if (lane <= 54) {
+          // positions < 256 go into this frame's input; lane 54's last three land in the input's zero padding, which is never read
+          const float4 wh = *reinterpret_cast<const float4 *>(tail_w[lane - 46]);
+          const v2f h01 = V2(hi[0], hi[1]) * V2(wh.x, wh.y), h23 = V2(hi[2], hi[3]) * V2(wh.z, wh.w);
+          if (emit) *reinterpret_cast<float4 *>(&mem[kIn2 + 183 + 4 * lane]) = make_float4(h01.x, h01.y, h23.x, h23.y);
         }
       }
       } else {
         // short blocks: every sample enters twice, E = W[pos & 31] x (second half of block q-1's... first half of the
         // NEXT block's input) and H = x W[31 - (pos & 31)]; the frame starts with the overlap and the 39 delayed samples
         if (emit) {
-          if (lane < 32) mem[kE2 + lane] = S.pre2[lane];
+          if (lane < 32) mem[kE2 + lane] = S.pre2[1 + lane];
           if (lane < 39) {
-            const float x = S.pre2[32 + lane];
+            const float x = S.pre2[33 + lane];
             mem[kE2 + 32 + lane] = win[lane & 31] * x;
             mem[kH2 + lane] = x * win[31 - (lane & 31)];
           }
@@ -375,8 +386,8 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
           if (pos < 256) {
             const float e = win[pos & 31] * x;
             if (emit) { mem[kE2 + 32 + pos] = e; mem[kH2 + pos] = x * win[31 - (pos & 31)]; }
-            if (pos >= 224) S.pre2[pos - 224] = e;
-          } else S.pre2[32 + pos - 256] = x;
+            if (pos >= 224) S.pre2[1 + pos - 224] = e;
+          } else S.pre2[33 + pos - 256] = x;
         }
       }
     }
