@@ -564,7 +564,9 @@ hipEvent_t take_event(c1_ctx *ctx) {
     return e;
   }
   hipEvent_t e;
-  hipEventCreate(&e);
+  // timing marks only: nobody reads memory behind them, so no system-scope release (a cache write-back per record, ~5 us of
+  // idle stream each; tools/prof_cost.py)
+  hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
   return e;
 }
 struct ScopedTiming {

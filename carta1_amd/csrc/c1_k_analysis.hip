@@ -71,6 +71,21 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   // its own warm-up frame; otherwise one item = this workgroup's run of L.run_frames frames
   const bool listed = L.unit_list != nullptr;
   const int64_t n_items = listed ? (int64_t)*L.unit_count : (int64_t)gridDim.x;
+  // lane-only geometry of the long-block MDCT core and the LDS copies of small tables: once per wave, not once per listed unit
+  R4Geometry G4 = r4_geometry(lane0);
+  const SfLong SFL = sf_long_geometry(lane0);
+  if constexpr (ALL_LONG) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      S.late[j][lane0] = r4_late_word(G4, j);
+      G4.cx[j] = G4.cy[j] = G4.post_tab[j] = 0;             // not carried through the loop
+    }
+    S.sfw[lane0] = (uint32_t)SFL.src | ((uint32_t)SFL.b << 13) | (SFL.wide ? 1u << 19 : 0u) | (SFL.store ? 1u << 20 : 0u);
+    if (lane0 < 32) S.win[lane0] = C1_TABLES(L.tables)->window[lane0];
+  }
+  const SfLong SFM = sf_geometry(lane0, O->modes[0], O->modes[1], O->modes[2]);     // used when !ALL_LONG
+  const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
+  const TablesRsrc RT = tables_rsrc(L.tables);
   for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
   const int64_t listed_unit = listed ? (int64_t)L.unit_list[item] : 0;
   const int ch = listed ? (int)(listed_unit % L.channels) : (int)(blockIdx.x % L.channels);
@@ -87,21 +102,6 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
     for (int i = lane; i < 96; i += 64) S.ovl[i] = 0.0f;
   }
   float ov0 = 0.0f, ov1 = 0.0f, ov2 = 0.0f;     // lanes 0..31: mdctOverlap of the three bands, carried in registers
-  // lane-only geometry of the long-block MDCT core, computed once (everything else is re-derived per frame)
-  R4Geometry G4 = r4_geometry(lane0);
-  const SfLong SFL = sf_long_geometry(lane0);
-  if constexpr (ALL_LONG) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      S.late[j][lane0] = r4_late_word(G4, j);
-      G4.cx[j] = G4.cy[j] = G4.post_tab[j] = 0;             // not carried through the loop
-    }
-    S.sfw[lane0] = (uint32_t)SFL.src | ((uint32_t)SFL.b << 13) | (SFL.wide ? 1u << 19 : 0u) | (SFL.store ? 1u << 20 : 0u);
-    if (lane0 < 32) S.win[lane0] = C1_TABLES(L.tables)->window[lane0];
-  }
-  const SfLong SFM = sf_geometry(lane0, O->modes[0], O->modes[1], O->modes[2]);     // used when !ALL_LONG
-  const MixGeometry GM = mix_geometry(lane0, FrameModes{O->modes[0], O->modes[1], O->modes[2]});   // used when !ALL_LONG
-  const TablesRsrc RT = tables_rsrc(L.tables);
   wave_fence();
 
   const int64_t f_end = (f0 + run_frames < L.frames) ? f0 + run_frames : L.frames;

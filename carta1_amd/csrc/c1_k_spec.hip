@@ -243,9 +243,12 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     return *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(tab) + (byte_offset - kSpecTabBase));
   };
   const uint32_t n_slots = (uint32_t)((L.frames + L.run_frames - 1) / L.run_frames) * (uint32_t)L.channels;
-  const uint32_t vblock = blockIdx.x * kSpecWaves + (uint32_t)wave;
-  if (vblock >= n_slots) return;
-  const uint32_t slot = L.spread_bits > 0 ? spread_block(vblock, n_slots, L.spread_bits) : vblock;
+  // the bijection moves whole workgroups: the four waves of one take four consecutive (run, channel) pairs, i.e. the same
+  // material, so a tonal stretch gives its workgroups back at once (with four unrelated pairs a workgroup kept its LDS and
+  // its four wave slots until the last non-tonal run was through: a quarter of tonal runs left that share of the slots idle)
+  const uint32_t group = L.spread_bits > 0 ? spread_block(blockIdx.x, gridDim.x, L.spread_bits) : blockIdx.x;
+  const uint32_t slot = group * kSpecWaves + (uint32_t)wave;
+  if (slot >= n_slots) return;
   const int ch = (int)(slot % (uint32_t)L.channels);
   const int64_t f0 = (int64_t)(slot / (uint32_t)L.channels) * L.run_frames;
   const float *__restrict__ pcm = L.pcm[ch];
@@ -779,7 +782,7 @@ void c1k_launch_analysis_spec(const C1EncodeLaunch &L0, bool all_short, hipStrea
   const dim3 grid((unsigned)((n_slots + kSpecWaves - 1) / kSpecWaves)), block(C1_WAVE * kSpecWaves);
   static const bool no_spread = getenv("C1_NO_SPREAD") != nullptr;     // experiments: runs in stream order
   L.spread_bits = 0;
-  if (!no_spread) while ((1ll << L.spread_bits) < n_slots) L.spread_bits++;
+  if (!no_spread) while ((1ll << L.spread_bits) < (int64_t)grid.x) L.spread_bits++;   // the bijection is over workgroups
   if (all_short) hipLaunchKernelGGL((k_analysis_spec<true>), grid, block, 0, stream, L);
   else hipLaunchKernelGGL((k_analysis_spec<false>), grid, block, 0, stream, L);
 }
