@@ -516,6 +516,27 @@ int ensure_workspace(c1_ctx *ctx, int64_t units) {
   return C1_OK;
 }
 
+// Frames per chunk of an encode call.  Every kernel of the chain ends in a tail of draining workgroups and the allocation's
+// later rounds are bound by the latency of one heap run whatever their list's length, so a batch is best kept in ONE chunk
+// (BASELINE configs[3]'s share of 12.5 M stereo frames: 130.7 M frames/s in chunks of 1 M, 138.9 M in chunks of 4 M, 144.7 M
+// in one) -- the workspace costs 2.6 KB per unit (4.8 KB with transient detection) and this part has 288 GB.  The configured
+// chunk (C1_CHUNK_FRAMES, default 2^24 frames) is cut down to what the device can hold right now next to the caller's
+// buffers; a workspace that is already large enough is used as it is.
+constexpr size_t kWsBytesPerUnit = 512 * sizeof(float) + kSideBytes + kAllocBytes + kCandidateBytes + 8 * sizeof(uint32_t) + kEpsFloats * sizeof(float) + 4 * sizeof(uint32_t);
+constexpr size_t kDetectWsBytesPerUnit = 512 * sizeof(float) + kFeatureWsDoubles * sizeof(double) + 1 + 3 * sizeof(uint32_t);
+int64_t chunk_for_call(c1_ctx *ctx, int64_t frames, int channels, bool detect) {
+  const int64_t want = std::min(frames, ctx->chunk_frames);
+  if (want * channels <= ctx->ws_units && (!detect || want * channels <= ctx->det_units)) return want;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return std::min<int64_t>(want, 1048576); }
+  const size_t sets = (ctx->pipeline || ctx->overlap) ? 2 : 1, det_sets = ctx->pipeline ? 2 : 1;
+  size_t avail = free_b + (size_t)ctx->ws_units * kWsBytesPerUnit * sets;          // the present workspace is freed before it grows
+  size_t per_unit = kWsBytesPerUnit * sets;
+  if (detect) { avail += (size_t)ctx->det_units * kDetectWsBytesPerUnit * det_sets; per_unit += kDetectWsBytesPerUnit * det_sets; }
+  const int64_t fit = (int64_t)((double)avail * 0.9 / (double)per_unit) / channels;
+  return std::max<int64_t>(16, std::min(want, fit));
+}
+
 // the lists of the speculative path in workspace half p: counts at [0, kListHead), then the redo, reallocation,
 // re-analysis and deferred-run lists, ws_units entries each
 void bind_lists(c1_ctx *ctx, int p, C1EncodeLaunch *L) {
@@ -634,8 +655,8 @@ int encode_device_impl(c1_ctx *ctx, const float *const *pcm, int channels, int64
   if (ctx->profiling && ctx->timing_depth == 0) reset_timings(ctx);
   if (frames == 0) return C1_OK;
   const bool detect = opts->fixed_block_modes[0] < 0;
-  const int64_t chunk = ctx->chunk_frames;
   const bool taps = coefs_tap || side_tap || alloc_tap;
+  const int64_t chunk = taps ? ctx->chunk_frames : chunk_for_call(ctx, frames, channels, detect);
   if ((rc = ensure_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (detect && (rc = ensure_detect_workspace(ctx, (taps ? frames : std::min(frames, chunk)) * channels))) return rc;
   if (taps && (!coefs_tap || !side_tap || !alloc_tap)) return fail(C1_ERR_ARG, "coefs, side and alloc taps must be given together");
@@ -995,7 +1016,7 @@ int c1_ctx_create(int device, void *hip_stream, c1_ctx **out) {
     ctx->pipeline = pl ? atoi(pl) != 0 : false;   // measured: no gain while one kernel's grid already owns every CU's LDS
   }
   const char *env = getenv("C1_CHUNK_FRAMES");
-  ctx->chunk_frames = env ? atoll(env) : 1048576;
+  ctx->chunk_frames = env ? atoll(env) : (int64_t)1 << 24;   // chunk_for_call() cuts it down to what fits
   if (ctx->chunk_frames < 16) ctx->chunk_frames = 16;
   // the allocation work list packs (unit << 3 | candidate) into 32 bits and unit lists are 32-bit: a chunk holds
   // fewer than 2^29 units, with room to spare
