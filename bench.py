@@ -480,8 +480,9 @@ def main():
         f3 = args.config3_frames
         p3 = generate(f3, 'pink', (3, 4), 0)
         o3 = options_for(None, 1.0)
-        # untimed warm-up on the first chunk: the detection workspace (4.3 GB per 1 M-frame chunk) is allocated on first use
-        wu = encode_run(p3, min(f3, 1 << 20), o3.to_c(), 1, 0)
+        # untimed warm-up at full size: the library keeps the batch in one chunk and allocates its workspace (4.8 KB per unit
+        # with detection: 100 GB here) on first use
+        wu = encode_run(p3, f3, o3.to_c(), 1, 0)
         del wu
         u3, el_e, km_e, _, _, _ = encode_run(p3, f3, o3.to_c(), 1, 0)
         det_units, det_open = ctx.detection_stats()

@@ -115,12 +115,13 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
   // spot), and taken delivery of at a point every path through the frame passes, BEFORE the frame's stores are issued: loads
   // and stores share one in-order counter on this part (vmcnt), so a wait for a load behind a store is a wait for the store
   // to reach memory as well (c1_k_spec.hip, tools/isa_waits.py).
-  float4 pre_a, pre_b;
+  typedef float v4f __attribute__((ext_vector_type(4)));   // whole 16-byte register groups (as eight scalars the asm cost eight moves a frame)
+  v4f pre_a, pre_b;
   auto deliver = [&]() {
-    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+    asm volatile("" : "+v"(pre_a), "+v"(pre_b));
   };
   {
-    const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
+    const v4f *p4 = reinterpret_cast<const v4f *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
     deliver();
   }
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(C1_WAVE, ALL_LONG ? 4 : 3) void k_analysis_fast(C1E
 
     // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
     {
-      const float4 a = pre_a, b = pre_b;
+      const v4f a = pre_a, b = pre_b;
       {
-        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
+        const v4f *p4 = reinterpret_cast<const v4f *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
         pre_a = p4[lane]; pre_b = p4[64 + lane];
       }
       double *w1 = S.u.q1.w1;

@@ -558,12 +558,13 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
   int64_t f_first = f0 - 2;                                  // frame -2 rebuilds the QMF delay lines, frame -1 the magnitudes
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;
   if (f_first > f0) f_first = f0;
-  float4 pre_a, pre_b;
+  typedef float v4f __attribute__((ext_vector_type(4)));   // whole 16-byte register groups (as eight scalars the asm cost eight moves a frame)
+  v4f pre_a, pre_b;
   {
-    const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
+    const v4f *p4 = reinterpret_cast<const v4f *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
     // delivered before the loop: a load still pending at the loop's entry makes the compiler wait inside the loop, every frame
-    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+    asm volatile("" : "+v"(pre_a), "+v"(pre_b));
   }
   for (int64_t f = f_first; f < f_end; ++f) {
     // frame -1 of the whole batch is emitted too (slot row 0): frame 0 needs its features and its band tails
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
 
     // ---------------- qmfAnalysisStage (encoder.js:57-96) ----------------
     {
-      const float4 a = pre_a, b = pre_b;
+      const v4f a = pre_a, b = pre_b;
       double *w1 = S.u.q1.w1;
       if (lane < 46) w1[pidx<3>(lane)] = S.d1[lane];
       const int e0 = 46 + 4 * lane;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
     {
       // the next frame's PCM (the last frame asks for itself again: under a condition the loaded values are copied into the
       // loop-carried registers behind the load, i.e. waited for on the spot)
-      const float4 *p4 = reinterpret_cast<const float4 *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
+      const v4f *p4 = reinterpret_cast<const v4f *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
       pre_a = p4[lane]; pre_b = p4[64 + lane];
     }
     {
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(C1_WAVE, SPEC ? 4 : 3) void k_detect_features(C1Enc
     // of the loop passes, and before any store of this frame is issued: a load still pending on ONE path makes the compiler wait
     // at the top of the loop on ALL of them, and there the wait would sit right behind the frame's stores (loads and stores
     // share one in-order counter on this part, vmcnt)
-    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+    asm volatile("" : "+v"(pre_a), "+v"(pre_b));
     if (qmf_only) { wave_fence(); continue; }
     const int64_t slot = (f + 1) * L.channels + ch;
     // Every store of the frame (bands, feature record) comes LAST: a wait for a load issued behind a store -- the table
@@ -898,17 +899,18 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   const double win_hi = C1_TABLES(L.tables)->window[31 - (lane0 & 31)];
   uint32_t i = blockIdx.x;
   if (i >= count) return;
-  float4 pre_a, pre_b, pre_t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  typedef float v4f __attribute__((ext_vector_type(4)));   // whole 16-byte register groups for the delivery asm below
+  v4f pre_a, pre_b, pre_t = {0.0f, 0.0f, 0.0f, 0.0f};
   int pre_mode = 0;
   bool pre_have = false;                                     // wave-uniform: the fetched unit has a previous frame in the workspace
   auto fetch = [&](int64_t u) {
     const int64_t slot = u + L.channels;
-    const float4 *p4 = reinterpret_cast<const float4 *>(bands_ws + (slot << 9));
+    const v4f *p4 = reinterpret_cast<const v4f *>(bands_ws + (slot << 9));
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
     pre_have = ((L.channels == 2 ? u >> 1 : u) - 1 >= -(int64_t)L.halo_frames);
     // the tails are loaded unconditionally (from the unit's own slot where there is no previous frame; every lane: tail_src
     // stays inside the slot) and masked when they are used: a load under a condition is waited for where it is issued
-    pre_t = *reinterpret_cast<const float4 *>(bands_ws + ((pre_have ? slot - L.channels : slot) << 9) + tail_src);
+    pre_t = *reinterpret_cast<const v4f *>(bands_ws + ((pre_have ? slot - L.channels : slot) << 9) + tail_src);
     if (!LONG) pre_mode = modes[u];
   };
   // The samples of the NEXT unit are requested while this one is transformed, unconditionally (past the end of the list the
@@ -917,8 +919,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   // share one in-order counter on this part (vmcnt), so a wait for a load behind a store is a wait for the store as well.
   auto listed = [&](uint32_t k) -> int64_t { return (int64_t)list[k < count ? k : count - 1]; };
   auto deliver = [&]() {
-    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
-    asm volatile("" : "+v"(pre_t.x), "+v"(pre_t.y), "+v"(pre_t.z), "+v"(pre_t.w), "+v"(pre_mode));
+    asm volatile("" : "+v"(pre_a), "+v"(pre_b), "+v"(pre_t), "+v"(pre_mode));
   };
   int64_t unit = listed(i);
   int64_t unit_next = listed(i + gridDim.x);
@@ -927,14 +928,15 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   for (; i < count; i += gridDim.x) {
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
-    const float4 a = pre_a, b = pre_b, t = (pre_have && lane < 24) ? pre_t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const v4f a = pre_a, b = pre_b, t = (pre_have && lane < 24) ? pre_t : zero4;
     const int mode_byte = LONG ? 0 : __builtin_amdgcn_readfirstlane(pre_mode);
     const int64_t unit_now = unit;
     unit = unit_next;
     fetch(unit);
     unit_next = listed(i + 2 * gridDim.x);
-    reinterpret_cast<float4 *>(S.band)[lane] = a;
-    reinterpret_cast<float4 *>(S.band)[64 + lane] = b;
+    reinterpret_cast<v4f *>(S.band)[lane] = a;
+    reinterpret_cast<v4f *>(S.band)[64 + lane] = b;
     if (lane < 24) {
       // mdctOverlap of the previous frame (applyTailWindowing, encoder.js:309-316): W[k] * tail sample
       float4 o;

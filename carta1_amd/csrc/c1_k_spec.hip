@@ -281,12 +281,13 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
   int64_t f_first = f0 - 1;                   // one frame of history rebuilds the state
   if (f_first < -(int64_t)L.halo_frames) f_first = -(int64_t)L.halo_frames;
   if (f_first > f0) f_first = f0;
-  float4 pre_a, pre_b;
+  typedef float v4f __attribute__((ext_vector_type(4)));   // whole 16-byte register groups: the delivery asm below takes them as they are
+  v4f pre_a, pre_b;
   {
-    const float4 *p4 = reinterpret_cast<const float4 *>(pcm + f_first * 512);
+    const v4f *p4 = reinterpret_cast<const v4f *>(pcm + f_first * 512);
     pre_a = p4[lane0]; pre_b = p4[64 + lane0];
     // delivered before the loop: a load still pending at the loop's entry makes the compiler wait at the top of the loop, every frame
-    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+    asm volatile("" : "+v"(pre_a), "+v"(pre_b));
   }
   uint32_t deferred_from = 0xffffffffu;       // first unit of the part of this run that goes to the exact kernels (none)
   unsigned long long open_bits = 0ull;        // frames of this run whose scale-factor guard stayed open (wave-uniform)
@@ -294,11 +295,18 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     const bool emit = (f >= f0);
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
+    if constexpr (!SHORT) {
+      // the MDCT's base values pass through an opaque asm once per frame (see there) -- HERE, where every path through the
+      // frame passes: on the emitting path alone the loop header saw two versions of them (the warm-up frame's untouched
+      // ones) and the emitting path paid 23 register moves a frame to keep them apart
+      asm volatile("" : "+v"(B0.ia0), "+v"(B0.ic0), "+v"(B0.q2), "+v"(B0.ib), "+v"(B0.id), "+v"(B0.pt0));
+      asm volatile("" : "+v"(B0.za), "+v"(B0.zb), "+v"(B0.zc), "+v"(B0.zd), "+v"(B0.g));
+    }
 
     // ---------------- stage-1 work buffer, PCM energy ----------------
     float P;
     {
-      const float4 a = pre_a, b = pre_b;
+      const v4f a = pre_a, b = pre_b;
       // sample 4 lane + j of the frame sits at work index 46 + 4 lane + j: shifted by two samples against the lanes'
       // 16-byte groups.  Each lane takes the last two samples of its left neighbour (DPP wave shift) and writes
       // whole groups; the delay line is written afterwards and covers the two slots lane 0 filled with junk.
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
         // the next frame's PCM: requested once the window registers are free, used a frame later.  Unconditional (the
         // last frame of a run asks for itself again): under a condition the loaded values were copied into the
         // loop-carried registers right behind the load, i.e. waited for on the spot
-        const float4 *p4 = reinterpret_cast<const float4 *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
+        const v4f *p4 = reinterpret_cast<const v4f *>(pcm + ((f + 1 < f_end) ? f + 1 : f) * 512);
         pre_a = p4[lane]; pre_b = p4[64 + lane];
       }
       if (lane < 46) { S.d1[lane] = mem[w1_phys(512 + lane)]; mem[kR2 + lane] = S.d2[lane]; }
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     // at a point every path to the top of the loop passes: a load still pending on one path (the warm-up frame's `continue`)
     // makes the compiler wait at the top of the loop on all of them.
     if (!emit) {
-      asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+      asm volatile("" : "+v"(pre_a), "+v"(pre_b));
       continue;
     }
 
@@ -467,8 +475,6 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     // (the base values pass through an opaque asm once per frame: otherwise every address derived from them is
     // loop invariant, gets hoisted out of the frame loop and spilled)
     // (in place, on the loop-carried registers themselves: through a per-frame copy it cost 14 register moves a frame)
-    asm volatile("" : "+v"(B0.ia0), "+v"(B0.ic0), "+v"(B0.q2), "+v"(B0.ib), "+v"(B0.id), "+v"(B0.pt0));
-    asm volatile("" : "+v"(B0.za), "+v"(B0.zb), "+v"(B0.zc), "+v"(B0.zd), "+v"(B0.g));
     const SpecBase &B = B0;
     {
       const int qb = 4 * B.q2;                               // bytes between the pre-twiddle pairs of points q apart
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     }
     // ---------------- the bound, coefficients out, scale-factor indices with their guard ----------------
     const int64_t unit = f * L.channels + ch;
-    asm volatile("" : "+v"(pre_a.x), "+v"(pre_a.y), "+v"(pre_a.z), "+v"(pre_a.w), "+v"(pre_b.x), "+v"(pre_b.y), "+v"(pre_b.z), "+v"(pre_b.w));
+    asm volatile("" : "+v"(pre_a), "+v"(pre_b));
     {
       // streaming stores (the packing kernel reads these 4 GB long after they have left the cache): -2 % of the kernel
       v4f *dst = reinterpret_cast<v4f *>(L.coefs + (unit << 9));
