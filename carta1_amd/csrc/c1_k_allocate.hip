@@ -38,6 +38,7 @@ namespace {
 // heap frees, so when the loop ends slots [0, initial size) hold every BFU with its final word length.
 constexpr int kHeapSlotsPerLane = 52 + 1;   // + one zero sentinel behind the last slot (13 568 bytes per wave: 12 waves per CU; 54 rows leave 11)
 constexpr uint32_t kLow = 0x1FFFFFu;
+constexpr uint32_t kSentinel = 52u;           // rank 0, word length 0, "BFU 52": the gather behind the heap run sends it to the spare slot
 constexpr int kCandBytes = kCandidateBytes;  // per unit: 8 totals (double) + 8 x 32-byte results + 8 lower bounds
 constexpr double kAlive = -1.0;              // total of a candidate that may still win and has not been evaluated (real totals are >= 0)
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
     }
   }
   const int hs0 = hs;
-  for (int k = hs; k < kHeapSlotsPerLane; k++) hp[k * 64] = 0u;   // sentinels
+  for (int k = hs; k < kHeapSlotsPerLane; k++) hp[k * 64] = kSentinel;   // rank 0: below every live entry
   for (int i = (hs >> 1) - 1; i >= 0; i--) {               // heapify (:238-241); per-lane trip counts
     const int l = 2 * i + 1;
     heap_sift_down(hp, 52, i, hp[i * 64], hp[l * 64], hp[(l + 1) * 64], true);
@@ -143,28 +144,77 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
       const int i1 = tr0 ? 2 : 1;
       const uint32_t *src = hp + (2 * i1 + 1) * 64;
       const uint32_t el = src[0], er = src[64];
+      // both pairs of grandchildren (slots 4 i1 + 3 .. 4 i1 + 6 <= 14: always inside the lane's slots) are requested with the
+      // children: one LDS round trip decides two levels -- the loop is a chain of dependent round trips, not of instructions
+      const uint32_t g0 = src[(2 * i1 + 2) * 64], g1 = src[(2 * i1 + 3) * 64], g2 = src[(2 * i1 + 4) * 64], g3 = src[(2 * i1 + 5) * 64];
       const bool tr1 = er > max(el | kLow, vmax);
       const bool tl1 = !tr1 && el > vmax;
       const bool mv1 = mv0 && (tr1 || tl1);
       const uint32_t val = mv1 ? (tr1 ? er : el) : v;
       if (mv0) { if (tr0) r2 = val; else r1 = val; }
+      // levels 2..5 unrolled (a heap of 52 has six): node i2 in slots 3..6 against its children (the grandchildren above),
+      // then ONE more round trip for the children (slots 15..30) and grandchildren (31..62, clamped to the sentinel slot,
+      // whose rank 0 never wins) of the node in slots 7..14 it moves to.  Two round trips per step where the loop of
+      // heap_sift_down made up to five (one per level and one more to find that the last level has no children); a
+      // lane that stops early just stops writing.
       {
         const int i2 = 2 * i1 + 1 + (tr1 ? 1 : 0);
-        const uint32_t *s2 = hp + (2 * i2 + 1) * 64;     // i2 <= 6: children 7..14 always inside the lane's slots
-        heap_sift_down(hp, 52, i2, v, s2[0], s2[64], mv1);
+        const uint32_t c0 = tr1 ? g2 : g0, c1 = tr1 ? g3 : g1;
+        const bool tr2 = c1 > max(c0 | kLow, vmax);
+        const bool tl2 = !tr2 && c0 > vmax;
+        const bool mv2 = mv1 && (tr2 || tl2);
+        if (mv1) hp[i2 * 64] = mv2 ? (tr2 ? c1 : c0) : v;
+        if (__builtin_amdgcn_ballot_w64(mv2) != 0) {
+          const int i3 = 2 * i2 + 1 + (tr2 ? 1 : 0);                  // 7..14
+          const uint32_t *s3 = hp + (2 * i3 + 1) * 64;                // children: slots 15..30
+          const uint32_t d0 = s3[0], d1 = s3[64];
+          const int q = 4 * i3 + 3;                                   // grandchildren: slots 31..62
+          const uint32_t h0 = hp[min(q, 52) * 64], h1 = hp[min(q + 1, 52) * 64], h2 = hp[min(q + 2, 52) * 64], h3 = hp[min(q + 3, 52) * 64];
+          const bool tr3 = d1 > max(d0 | kLow, vmax);
+          const bool tl3 = !tr3 && d0 > vmax;
+          const bool mv3 = mv2 && (tr3 || tl3);
+          if (mv2) hp[i3 * 64] = mv3 ? (tr3 ? d1 : d0) : v;
+          const int i4 = 2 * i3 + 1 + (tr3 ? 1 : 0);                  // 15..30
+          const uint32_t e0 = tr3 ? h2 : h0, e1 = tr3 ? h3 : h1;
+          const bool tr4 = e1 > max(e0 | kLow, vmax);
+          const bool tl4 = !tr4 && e0 > vmax;
+          const bool mv4 = mv3 && (tr4 || tl4);
+          if (mv3) hp[i4 * 64] = mv4 ? (tr4 ? e1 : e0) : v;
+          if (mv4) hp[(2 * i4 + 1 + (tr4 ? 1 : 0)) * 64] = v;          // slots 31..51: no children
+        }
       }
     }
     run = run && remaining >= 4 && hs > 0;
   }
   hp[0] = r0; hp[64] = r1; hp[128] = r2;
-  // every BFU that ever entered the heap now sits in slots [0, hs0) with its final word length
-  res0 = res1 = res2 = res3 = 0;
-  for (int k = 0; k < hs0; k++) {
-    const uint32_t e = hp[k * 64];
-    const int b = e & 63;
-    const uint64_t v = (uint64_t)((e >> 6) & 15) << ((b & 15) * 4);
-    const int w = b >> 4;
-    res0 |= w == 0 ? v : 0; res1 |= w == 1 ? v : 0; res2 |= w == 2 ? v : 0; res3 |= w == 3 ? v : 0;
+  // Every BFU that ever entered the heap now sits in slots [0, hs0) with its final word length; the slots behind hold the
+  // sentinel, which names slot 52.  The word lengths are put in BFU order through the lane's own column of the heap: the
+  // top byte of slot b takes BFU b's word length (a byte store: the rank bits up there are done with, and the low bits
+  // that name an unread entry's BFU and word length stay as they are), then the 52 top bytes are read back in order and
+  // packed with constant shifts.  6 vector instructions per BFU; selecting one of four 64-bit words by a lane-varying
+  // index cost 25 (1 300 of the 8 300 a wave of k_alloc_first issued).
+  (void)hs0;
+  {
+    uint8_t *hb = reinterpret_cast<uint8_t *>(hp);
+#pragma unroll
+    for (int k = 0; k < 52; k++) hb[k * 256 + 3] = 0;
+#pragma unroll
+    for (int k0 = 0; k0 < 52; k0 += 8) {
+      uint32_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (k0 + j < 52) e[j] = hp[(k0 + j) * 64];
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (k0 + j < 52) hb[(e[j] & 63u) * 256 + 3] = (uint8_t)((e[j] >> 6) & 15u);
+    }
+    uint32_t d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      d[i] = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (8 * i + j < 52) d[i] |= (hp[(8 * i + j) * 64] >> 24) << (4 * j);
+    }
+    res0 = (uint64_t)d[0] | ((uint64_t)d[1] << 32); res1 = (uint64_t)d[2] | ((uint64_t)d[3] << 32);
+    res2 = (uint64_t)d[4] | ((uint64_t)d[5] << 32); res3 = (uint64_t)d[6] | ((uint64_t)d[7] << 32);
   }
   // calculateTotalDistortion (:157-190): sequential double sum, index ascending
   total = 0.0;
