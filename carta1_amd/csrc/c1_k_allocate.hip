@@ -80,8 +80,10 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
   const __attribute__((address_space(4))) double *biased = (const __attribute__((address_space(4))) double *)O->biased;
   const bool affine = O->rank_affine != 0;
   const int ka = O->rank_a, kb = O->rank_b, kc = O->rank_c, koff = O->rank_off;
+  // (24-bit multiplies: every factor is below 64 in magnitude, and the full 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+  const int nkb = -kb, kc_off = kc + koff;
   auto rank_of = [&](int s, int wl) -> uint32_t {
-    if (affine) return (uint32_t)(ka * s + (wl == 0 ? kc : -kb * wl - kb) + koff);
+    if (affine) return (uint32_t)(wl == 0 ? __mul24(ka, s) + kc_off : __mul24(ka, s) + koff + __mul24(nkb, wl + 1));
     return rank_t[s * 16 + (wl & 15)];
   };
   int remaining = 212 * 8 - 40 - 10 * n;                   // bitallocation.js:97-100
