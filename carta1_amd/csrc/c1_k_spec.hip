@@ -61,7 +61,7 @@ static_assert(offsetof(C1DevTables, pre32_64) > offsetof(C1DevTables, win32) && 
 static_assert(kSpecWaves * sizeof(SpecLds) + kSpecTabFloats * 4 + 27 * 16 <= 32768, "speculative analysis: 5 workgroups of 4 waves per CU");
 constexpr int kE2 = 0, kH2 = 288, kE0 = kR2, kH0 = kR2 + 160, kE1 = kR2 + 288, kH1 = kR2 + 448;
 
-__device__ __forceinline__ int w1_phys(int v) { return 12 * (v >> 3) + (v & 7); }
+__device__ __forceinline__ int w1_phys(int v) { return __mul24(12, v >> 3) + (v & 7); }   // 24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate
 
 // D consecutive outputs of the decimating QMF from the lane's window w[0 .. 46 + 2 D), held as the pairs
 // W[k] = (w[2 k], w[2 k + 1]).  Output d uses w[2 d ..]:
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
       float lo[4], hi[4];
       if (own_block()) {
         v2f W[28];
-        const float4 *src = reinterpret_cast<const float4 *>(mem + 12 * lane);
+        const float4 *src = reinterpret_cast<const float4 *>(mem + __mul24(12, lane));
 #pragma unroll
         for (int k = 0; k < 14; k++) {
           const float4 t = src[3 * (k >> 1) + (k & 1)];      // floats 12 (k >> 1) + 4 (k & 1): blocks of 8 padded to 12
@@ -416,7 +416,12 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
         }
         qmf_core_f32<2>(W, T, lo, hi);
       } else { for (int d = 0; d < 2; d++) { lo[d] = mem[lane + d]; hi[d] = 1.0f; } }
-      if (lane < 46) S.d2[lane] = mem[kR2 + 256 + lane];
+      {
+        // (a lane index of its own: from `lane` the compiler derives this 4-byte-stride address as the window's 16-byte-stride
+        // one minus 12 lane -- a 64-bit multiply-add at a quarter of the issue rate)
+        const int ld = lane_for_this_frame(lane0);
+        if (ld < 46) S.d2[ld] = mem[kR2 + 256 + ld];
+      }
       if constexpr (!SHORT) {
       if (lane < 48) {
         if (emit) {
@@ -479,11 +484,12 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
     {
       const int qb = 4 * B.q2;                               // bytes between the pre-twiddle pairs of points q apart
       const v2f t0 = table_f2(RT, B.pt0), t1 = table_f2(RT, B.pt0 + 2 * qb);
-      const v2f t2 = table_f2(RT, B.pt0 + qb), t3 = table_f2(RT, B.pt0 + 3 * qb);
+      const v2f t2 = table_f2(RT, B.pt0 + qb), t3 = table_f2(RT, B.pt0 + __mul24(3, qb));
       const float a0 = mem[B.ia0], c0 = mem[B.ic0];
       const float a1 = mem[B.ia0 - 2 * B.q2], c1 = mem[B.ic0 + 2 * B.q2];
       const float a2 = mem[B.ia0 - B.q2], c2 = mem[B.ic0 + B.q2];
-      const float a3 = mem[B.ia0 - 3 * B.q2], c3 = mem[B.ic0 + 3 * B.q2];
+      const int q3 = __mul24(3, B.q2);
+      const float a3 = mem[B.ia0 - q3], c3 = mem[B.ic0 + q3];
       const float bb = mem[B.ib], dd = mem[B.id];             // the lane's one pair outside the zero padding (or unused)
       const float b0 = B.use_lo ? bb : 0.0f, d0 = B.use_lo ? dd : 0.0f;
       const float b3 = B.use_hi ? bb : 0.0f, d3 = B.use_hi ? dd : 0.0f;
@@ -633,8 +639,9 @@ __global__ __launch_bounds__(C1_WAVE * kSpecWaves, 5) void k_analysis_spec(C1Enc
       // streaming stores (the packing kernel reads these 4 GB long after they have left the cache): -2 % of the kernel
       v4f *dst = reinterpret_cast<v4f *>(L.coefs + (unit << 9));
       const v4f *src = reinterpret_cast<const v4f *>(coef);
-      __builtin_nontemporal_store(src[lane], &dst[lane]);
-      __builtin_nontemporal_store(src[64 + lane], &dst[64 + lane]);
+      const int lq = lane_for_this_frame(lane0);               // its own lane index, as for the delay line above: 16-byte stride here
+      __builtin_nontemporal_store(src[lq], &dst[lq]);
+      __builtin_nontemporal_store(src[64 + lq], &dst[64 + lq]);
     }
     // eps_b = cz_b Z_b + cw_b W + cl_b L + eabs  (DESIGN.md 3b); Z_b^2 = energy of the band's pre-twiddled points
     // (short blocks: of the block with the most energy; the coefficients then belong to 16-point transforms)
