@@ -387,6 +387,29 @@ __device__ __forceinline__ double2 table_pair(TablesRsrc R, int byte_offset) {
   __builtin_memcpy(&d, &v, sizeof d);
   return d;
 }
+// Where the exact long-block core (mdct_long_r4) reads its 16 lane-varying (cos, sin) pairs from: the tables in global memory
+// through the buffer resource, or a workgroup's copy in LDS of the two pieces it touches -- mdct_fwd256 | mdct_fwd512 (3 072
+// bytes) and the first 128 pairs of fft_tw (2 048 bytes), one behind the other.  A lane-varying global read is a cache round
+// trip on the counter the unit's loads and stores share; a kernel with nothing to hide it behind (k_mdct_bands: three such
+// round trips in the chain of every unit) reads the copy instead.  r4_geometry_lds() moves a geometry's byte offsets over.
+struct BufTab {
+  static constexpr int origin = 0;                         // byte offset of C1DevTables that offset 0 of this reader stands for
+  TablesRsrc R;
+  __device__ __forceinline__ double2 pair(int byte_offset) const { return table_pair(R, byte_offset); }
+};
+struct LdsTab {
+  static constexpr int origin = (int)offsetof(C1DevTables, mdct_fwd256);   // (of the forward tables; the twiddles sit behind them)
+  const char *base;
+  __device__ __forceinline__ double2 pair(int byte_offset) const { return *reinterpret_cast<const double2 *>(base + byte_offset); }
+};
+constexpr int kLdsTabFwdBytes = (128 + 256) * (int)sizeof(double), kLdsTabTwBytes = 128 * 2 * (int)sizeof(double);
+constexpr int kLdsTabBytes = kLdsTabFwdBytes + kLdsTabTwBytes;
+static_assert(offsetof(C1DevTables, mdct_fwd512) == offsetof(C1DevTables, mdct_fwd256) + 128 * sizeof(double), "the two forward tables are copied as one piece");
+// byte k of the copy <- byte of C1DevTables (16-byte granules)
+__device__ __forceinline__ int lds_tab_source(int k) {
+  return k < kLdsTabFwdBytes ? (int)offsetof(C1DevTables, mdct_fwd256) + k : (int)offsetof(C1DevTables, fft_tw) + (k - kLdsTabFwdBytes);
+}
+
 // =====================================================================================================
 // binary32 helpers of the speculative kernels (c1_k_spec.hip, the speculative transient detector in c1_k_detect.hip)
 // =====================================================================================================
@@ -462,11 +485,21 @@ __device__ __forceinline__ void r2_butterfly_unit(float2 &e, float2 &o) {
 
 // pre-twiddle pairs of round A, requested by the caller ahead of the core (before the second QMF stage)
 struct R4Early { double2 t0, t1, t2, t3; };
-__device__ __forceinline__ R4Early r4_early(const R4Geometry &G, TablesRsrc R) {
+template <class Tab>
+__device__ __forceinline__ R4Early r4_early_t(const R4Geometry &G, const Tab R) {
   R4Early e;
-  e.t0 = table_pair(R, G.pre_tab[0]); e.t1 = table_pair(R, G.pre_tab[1]);
-  e.t2 = table_pair(R, G.pre_tab[2]); e.t3 = table_pair(R, G.pre_tab[3]);
+  e.t0 = R.pair(G.pre_tab[0]); e.t1 = R.pair(G.pre_tab[1]);
+  e.t2 = R.pair(G.pre_tab[2]); e.t3 = R.pair(G.pre_tab[3]);
   return e;
+}
+__device__ __forceinline__ R4Early r4_early(const R4Geometry &G, TablesRsrc R) { return r4_early_t(G, BufTab{R}); }
+// the geometry's table offsets as offsets into the LDS copy (LdsTab)
+__device__ __forceinline__ R4Geometry r4_geometry_lds(R4Geometry G) {
+  constexpr int fwd = (int)offsetof(C1DevTables, mdct_fwd256), tw = (int)offsetof(C1DevTables, fft_tw) - kLdsTabFwdBytes;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { G.pre_tab[j] -= fwd; G.post_tab[j] -= fwd; }
+  G.twb -= tw; G.twc -= tw; G.twd -= tw;
+  return G;
 }
 // in: 1024 floats (in0 | in1 | in2, zero padded long-block inputs); z: 320 slots; coef: 512 floats (may share
 // memory with `in`: the inputs are dead once round A has read them)
@@ -478,13 +511,14 @@ __device__ __forceinline__ uint32_t r4_late_word(const R4Geometry &G, int j) {
   const int tab_base = G.band2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256);
   return (uint32_t)G.cx[j] | ((uint32_t)G.cy[j] << 9) | ((uint32_t)((G.post_tab[j] - tab_base) >> 4) << 18);
 }
-__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R, const R4Early &E,
-                                             const uint32_t *late = nullptr) {
+template <class Tab>
+__device__ __forceinline__ void mdct_long_r4_t(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, const Tab R, const R4Early &E,
+                                               const uint32_t *late = nullptr) {
   float2 x[4];
   // the lane-varying table values of the frame are requested up front: the loads are in flight while round A
   // reads its inputs, instead of one cache round trip in front of every round
   const double2 t0 = E.t0, t1 = E.t1, t2 = E.t2, t3 = E.t3;
-  const double2 wBa = table_pair(R, G.twb), wBb = table_pair(R, G.twb + 64), wBc = table_pair(R, G.twb + 128);
+  const double2 wBa = R.pair(G.twb), wBb = R.pair(G.twb + 64), wBc = R.pair(G.twb + 128);
   // ---- round A: pre-twiddle + stages 1, 2 ----
   {
     const float a0 = in[G.ia[0]], c0 = in[G.ic[0]], b0 = in[G.ib0], d0 = in[G.id0];
@@ -515,8 +549,8 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
     dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
   }
   // (the twiddles of rounds C and D take the registers the pre-twiddle pairs just left)
-  const double2 wCa = table_pair(R, G.twc), wCb = table_pair(R, G.twc + 256), wCc = table_pair(R, G.twc + 512);
-  const double2 wDa = table_pair(R, G.twd), wDb = table_pair(R, G.twd + 512);
+  const double2 wCa = R.pair(G.twc), wCb = R.pair(G.twc + 256), wCc = R.pair(G.twc + 512);
+  const double2 wDa = R.pair(G.twd), wDb = R.pair(G.twd + 512);
   wave_fence();
   // ---- round B: stages 4, 8 ----
   {
@@ -530,12 +564,12 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
   uint32_t lw[4] = {0u, 0u, 0u, 0u};
   int pt[4] = {G.post_tab[0], G.post_tab[1], G.post_tab[2], G.post_tab[3]};
   if (late) {
-    const int tab_base = G.band2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256);
+    const int tab_base = (G.band2 ? (int)offsetof(C1DevTables, mdct_fwd512) : (int)offsetof(C1DevTables, mdct_fwd256)) - Tab::origin;
 #pragma unroll
     for (int j = 0; j < 4; j++) { lw[j] = late[64 * j]; pt[j] = tab_base + (int)(lw[j] >> 18) * 16; }
   }
-  const double2 p0 = table_pair(R, pt[0]), p1 = table_pair(R, pt[1]);
-  const double2 p2 = table_pair(R, pt[2]), p3 = table_pair(R, pt[3]);
+  const double2 p0 = R.pair(pt[0]), p1 = R.pair(pt[1]);
+  const double2 p2 = R.pair(pt[2]), p3 = R.pair(pt[3]);
   wave_fence();
   // ---- round C: stages 16, 32 ----
   {
@@ -563,6 +597,10 @@ __device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *
     coef[cc & 511u] = f32(-rr * t.x - ii * t.y);
     coef[(cc >> 9) & 511u] = f32(-rr * t.y + ii * t.x);
   }
+}
+__device__ __forceinline__ void mdct_long_r4(const float *in, float2 *z, float *coef, const R4Geometry &G, TablesPtr T, TablesRsrc R, const R4Early &E,
+                                             const uint32_t *late = nullptr) {
+  mdct_long_r4_t(in, z, coef, G, T, BufTab{R}, E, late);
 }
 
 

@@ -876,17 +876,32 @@ struct alignas(16) MdctLds {
 // mdctStage + scale factors of one sound unit from the stored band samples; units are independent.  Two
 // instantiations work through the two lists k_detect_decide wrote: LONG (all three bands long, the common case;
 // lean enough for 4 waves per SIMD) and mixed (at least one short band).
+// LONG: four waves per workgroup, each with its own unit and LDS image; they share one copy of the (cos, sin) tables the long
+// core reads with lane-varying indices (LdsTab, c1_device.h): sixteen such reads a unit, which through the cache were three
+// round trips in the middle of every unit's chain, on the counter its loads and stores share.
+constexpr int kMdctWavesLong = 4;
 template <bool LONG>
-__global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, const float *__restrict__ bands_ws,
+__global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), 3) void k_mdct_bands(C1EncodeLaunch L, const float *__restrict__ bands_ws,
                                                                          const uint8_t *__restrict__ modes,
                                                                          const uint32_t *__restrict__ lists) {
-  __shared__ MdctLds S;
-  const int lane0 = threadIdx.x;
+  constexpr int kW = LONG ? kMdctWavesLong : 1;
+  __shared__ MdctLds Sw[kW];
+  __shared__ alignas(16) char tabs[LONG ? kLdsTabBytes : 16];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  MdctLds &S = Sw[wave];
+  const int lane0 = threadIdx.x & 63;
   int lane = lane0;
+  if constexpr (LONG) {
+    const char *src = reinterpret_cast<const char *>(L.tables);
+    for (int k = 16 * (int)threadIdx.x; k < kLdsTabBytes; k += 16 * C1_WAVE * kW)
+      *reinterpret_cast<uint4 *>(tabs + k) = *reinterpret_cast<const uint4 *>(src + lds_tab_source(k));
+    __syncthreads();                                   // the only time the waves of a workgroup meet
+  }
+  const LdsTab LT{tabs};
   const int64_t units = L.frames * L.channels;
   const uint32_t count = lists[LONG ? 0 : 1];
   const uint32_t *__restrict__ list = lists + 4 + (LONG ? 0 : units);
-  const R4Geometry G4 = r4_geometry(lane0);          // LONG
+  const R4Geometry G4 = r4_geometry_lds(r4_geometry(lane0));          // LONG: offsets into the LDS copy
   const SfLong SFL = sf_long_geometry(lane0);        // LONG
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
   const TablesRsrc RT = tables_rsrc(L.tables);
@@ -897,7 +912,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
   const double wt0 = C1_TABLES(L.tables)->window[tail_k & 31], wt1 = C1_TABLES(L.tables)->window[(tail_k + 1) & 31];
   const double wt2 = C1_TABLES(L.tables)->window[(tail_k + 2) & 31], wt3 = C1_TABLES(L.tables)->window[(tail_k + 3) & 31];
   const double win_hi = C1_TABLES(L.tables)->window[31 - (lane0 & 31)];
-  uint32_t i = blockIdx.x;
+  uint32_t i = blockIdx.x * kW + (uint32_t)wave;
+  const uint32_t stride = gridDim.x * kW;
   if (i >= count) return;
   typedef float v4f __attribute__((ext_vector_type(4)));   // whole 16-byte register groups for the delivery asm below
   v4f pre_a, pre_b, pre_t = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -922,10 +938,10 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     asm volatile("" : "+v"(pre_a), "+v"(pre_b), "+v"(pre_t), "+v"(pre_mode));
   };
   int64_t unit = listed(i);
-  int64_t unit_next = listed(i + gridDim.x);
+  int64_t unit_next = listed(i + stride);
   fetch(unit);
   deliver();
-  for (; i < count; i += gridDim.x) {
+  for (; i < count; i += stride) {
     TablesPtr T = tables_for_this_frame(L.tables);
     lane = lane_for_this_frame(lane0);
     const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -934,7 +950,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
     const int64_t unit_now = unit;
     unit = unit_next;
     fetch(unit);
-    unit_next = listed(i + 2 * gridDim.x);
+    unit_next = listed(i + 2 * stride);
     reinterpret_cast<v4f *>(S.band)[lane] = a;
     reinterpret_cast<v4f *>(S.band)[64 + lane] = b;
     if (lane < 24) {
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
       wave_fence();
-      mdct_long_r4(in0, S.zz.z, coef, G4, T, RT, r4_early(G4, RT));
+      mdct_long_r4_t(in0, S.zz.z, coef, G4, T, LT, r4_early_t(G4, LT));
       wave_fence();
     } else {
       const MixGeometry GM = mix_geometry(lane, M);
@@ -1016,7 +1032,8 @@ __global__ __launch_bounds__(C1_WAVE, 3) void k_mdct_bands(C1EncodeLaunch L, con
 void c1k_launch_mdct_bands(const C1EncodeLaunch &L, const float *bands_ws, const uint8_t *modes_ws, const uint32_t *lists_ws, hipStream_t stream) {
   const int64_t units = L.frames * L.channels;
   const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
-  hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+  const dim3 lgrid((unsigned)std::min<int64_t>((units + kMdctWavesLong - 1) / kMdctWavesLong, 256 * 48 / kMdctWavesLong)), lblock(C1_WAVE * kMdctWavesLong);
+  hipLaunchKernelGGL((k_mdct_bands<true>), lgrid, lblock, 0, stream, L, bands_ws, modes_ws, lists_ws);
   hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
 }
 
@@ -1044,7 +1061,8 @@ void c1k_launch_detect(const C1EncodeLaunch &L0, float *bands_ws, double *feat_w
   if (!L.coefs) return;                                      // decisions only (score taps)
   // both list kernels size their grids for the whole batch and stop at the device-side count
   const dim3 grid((unsigned)std::min<int64_t>(units, 256 * 48)), block(C1_WAVE);
-  hipLaunchKernelGGL((k_mdct_bands<true>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
+  const dim3 lgrid((unsigned)std::min<int64_t>((units + kMdctWavesLong - 1) / kMdctWavesLong, 256 * 48 / kMdctWavesLong)), lblock(C1_WAVE * kMdctWavesLong);
+  hipLaunchKernelGGL((k_mdct_bands<true>), lgrid, lblock, 0, stream, L, bands_ws, modes_ws, lists_ws);
   hipLaunchKernelGGL((k_mdct_bands<false>), grid, block, 0, stream, L, bands_ws, modes_ws, lists_ws);
 }
 
