@@ -152,7 +152,11 @@ int c1_ctx_set_decode_precision(c1_ctx *ctx, int binary32);
 
 /* device-resident: pcm[c] and units are DEVICE pointers; asynchronous on the context's stream: the call only enqueues
  * work and never waits for the device (it blocks only to grow the workspace on a first, larger call, or when the
- * options change while earlier calls are still queued) */
+ * options change while earlier calls are still queued).
+ * Device memory: the context keeps a workspace of 2.6 KB per sound unit (4.8 KB with transient detection) for the largest
+ * batch it has seen, until it is destroyed.  A batch is kept in one piece when that fits (up to 2^24 frames per channel, or
+ * C1_CHUNK_FRAMES from the environment) and is otherwise cut into chunks of what 90 % of the free device memory holds; the
+ * output is the same bytes either way. */
 int c1_encode_device(c1_ctx *ctx, const float *const *pcm, int channels, int64_t frames,
                      int halo_frames, const c1_encode_options *opts, uint8_t *units);
 /* host-resident: copies in, runs c1_encode_device, copies out, synchronises.
