@@ -31,12 +31,12 @@ namespace {
 // (bitallocation.js:226-231,267-269) exactly: equal priorities have equal rank, so the strict `>` of
 // siftDown (:325-331) -- and with it the tie order -- is reproduced.  With kLow = the 21 payload bits,
 // rank(a) > rank(b)  <=>  a > (b | kLow): one integer compare, no field extraction.  Rank 0 never occurs
-// in a live entry, so zeroed slots and parked entries (below) act as sentinels: no bounds checks in the sift.
+// in a live entry, so unused slots (kSentinel: rank 0) and parked entries (below) act as sentinels: no bounds checks in the sift.
 //
 // Heaps live in LDS as heap[slot][lane] (64 dwords per slot: conflict-free, the two children of a node one
 // ds_read2st64 apart).  An entry that leaves the heap is parked, rank cleared, in the slot the shrinking
 // heap frees, so when the loop ends slots [0, initial size) hold every BFU with its final word length.
-constexpr int kHeapSlotsPerLane = 52 + 1;   // + one zero sentinel behind the last slot (13 568 bytes per wave: 12 waves per CU; 54 rows leave 11)
+constexpr int kHeapSlotsPerLane = 52 + 1;   // + one sentinel slot behind the last (13 568 bytes per wave: 12 waves per CU; 54 rows leave 11)
 constexpr uint32_t kLow = 0x1FFFFFu;
 constexpr uint32_t kSentinel = 52u;           // rank 0, word length 0, "BFU 52": the gather behind the heap run sends it to the spare slot
 constexpr int kCandBytes = kCandidateBytes;  // per unit: 8 totals (double) + 8 x 32-byte results + 8 lower bounds
@@ -99,7 +99,6 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
       hs += (s != 0 && live) ? 1 : 0;
     }
   }
-  const int hs0 = hs;
   for (int k = hs; k < kHeapSlotsPerLane; k++) hp[k * 64] = kSentinel;   // rank 0: below every live entry
   for (int i = (hs >> 1) - 1; i >= 0; i--) {               // heapify (:238-241); per-lane trip counts
     const int l = 2 * i + 1;
@@ -189,13 +188,12 @@ __device__ __forceinline__ void run_candidate(uint32_t *hp, int n, const uint32_
     run = run && remaining >= 4 && hs > 0;
   }
   hp[0] = r0; hp[64] = r1; hp[128] = r2;
-  // Every BFU that ever entered the heap now sits in slots [0, hs0) with its final word length; the slots behind hold the
-  // sentinel, which names slot 52.  The word lengths are put in BFU order through the lane's own column of the heap: the
+  // Every BFU that ever entered the heap now sits in one of the first slots (as many as the heap started with) with its final
+  // word length; the slots behind hold the sentinel, which names slot 52.  The word lengths are put in BFU order through the lane's own column of the heap: the
   // top byte of slot b takes BFU b's word length (a byte store: the rank bits up there are done with, and the low bits
   // that name an unread entry's BFU and word length stay as they are), then the 52 top bytes are read back in order and
   // packed with constant shifts.  6 vector instructions per BFU; selecting one of four 64-bit words by a lane-varying
   // index cost 25 (1 300 of the 8 300 a wave of k_alloc_first issued).
-  (void)hs0;
   {
     uint8_t *hb = reinterpret_cast<uint8_t *>(hp);
 #pragma unroll
