@@ -873,45 +873,84 @@ struct alignas(16) MdctLds {
   } zz;
 };
 
+// the all-long instantiation's image (no staging area of frames with short blocks) and what its waves share: the tables the
+// long core reads with lane-varying indices (LdsTab, c1_device.h), WINDOW_SHORT, and lane-only geometry that is the same for
+// every wave -- the end-of-transform values of mdct_long_r4 (r4_late_word) and the scale-factor scan's word (as k_analysis_fast)
+struct alignas(16) MdctLdsLong {
+  alignas(16) float band[512];
+  alignas(16) float ovl[96];
+  alignas(4) uint8_t sfi[64];
+  union alignas(16) {
+    struct { alignas(16) float in0[256]; alignas(16) float in1[256]; alignas(16) float in2[512]; } i;
+    struct { alignas(16) float coef[512]; } c;
+  } a;
+  union alignas(16) {
+    float2 z[320];
+  } zz;
+};
+struct alignas(16) MdctShared {
+  alignas(16) char tabs[kLdsTabBytes];
+  alignas(16) double win[32];
+  uint32_t late[4][64];
+  uint32_t sfw[64];
+};
+struct alignas(16) MdctNoShared { alignas(16) char tabs[16]; alignas(16) double win[4]; uint32_t late[1][1]; uint32_t sfw[1]; };
+
 // mdctStage + scale factors of one sound unit from the stored band samples; units are independent.  Two
 // instantiations work through the two lists k_detect_decide wrote: LONG (all three bands long, the common case;
 // lean enough for 4 waves per SIMD) and mixed (at least one short band).
-// LONG: four waves per workgroup, each with its own unit and LDS image; they share one copy of the (cos, sin) tables the long
+// LONG: eight waves per workgroup, each with its own unit and LDS image; they share one copy of the (cos, sin) tables the long
 // core reads with lane-varying indices (LdsTab, c1_device.h): sixteen such reads a unit, which through the cache were three
-// round trips in the middle of every unit's chain, on the counter its loads and stores share.
-constexpr int kMdctWavesLong = 4;
+// round trips in the middle of every unit's chain, on the counter its loads and stores share (2.44 -> 2.29 ms per 2 M units
+// of config 3).  With the window and the lane-only geometry shared as well the kernel needs 114 registers and 9.2 KB of LDS
+// per wave: 4 waves per SIMD (two workgroups per CU) -- worth another 1 %: at 8 GB per launch and 3.6 TB/s the kernel is
+// closer to the memory system's rate for equal reads and writes (4.85 TB/s for a copy) than to any limit of its own.
+constexpr int kMdctWavesLong = 8;
 template <bool LONG>
-__global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), 3) void k_mdct_bands(C1EncodeLaunch L, const float *__restrict__ bands_ws,
+__global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), LONG ? 4 : 3) void k_mdct_bands(C1EncodeLaunch L, const float *__restrict__ bands_ws,
                                                                          const uint8_t *__restrict__ modes,
                                                                          const uint32_t *__restrict__ lists) {
   constexpr int kW = LONG ? kMdctWavesLong : 1;
-  __shared__ MdctLds Sw[kW];
-  __shared__ alignas(16) char tabs[LONG ? kLdsTabBytes : 16];
+  using Lds = typename std::conditional<LONG, MdctLdsLong, MdctLds>::type;
+  __shared__ Lds Sw[kW];
+  __shared__ typename std::conditional<LONG, MdctShared, MdctNoShared>::type SH;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  MdctLds &S = Sw[wave];
+  Lds &S = Sw[wave];
   const int lane0 = threadIdx.x & 63;
   int lane = lane0;
+  R4Geometry G4 = r4_geometry(lane0);                // LONG
   if constexpr (LONG) {
+    if (wave == 0) {
+      const SfLong SFL = sf_long_geometry(lane0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) SH.late[j][lane0] = r4_late_word(G4, j);
+      SH.sfw[lane0] = (uint32_t)SFL.src | ((uint32_t)SFL.b << 13) | (SFL.wide ? 1u << 19 : 0u) | (SFL.store ? 1u << 20 : 0u);
+      if (lane0 < 32) SH.win[lane0] = C1_TABLES(L.tables)->window[lane0];
+    }
     const char *src = reinterpret_cast<const char *>(L.tables);
     for (int k = 16 * (int)threadIdx.x; k < kLdsTabBytes; k += 16 * C1_WAVE * kW)
-      *reinterpret_cast<uint4 *>(tabs + k) = *reinterpret_cast<const uint4 *>(src + lds_tab_source(k));
+      *reinterpret_cast<uint4 *>(SH.tabs + k) = *reinterpret_cast<const uint4 *>(src + lds_tab_source(k));
     __syncthreads();                                   // the only time the waves of a workgroup meet
+#pragma unroll
+    for (int j = 0; j < 4; j++) G4.cx[j] = G4.cy[j] = G4.post_tab[j] = 0;   // read back from SH.late at the end of every transform
+    G4 = r4_geometry_lds(G4);                          // table offsets -> offsets into SH.tabs
   }
-  const LdsTab LT{tabs};
+  const LdsTab LT{SH.tabs};
   const int64_t units = L.frames * L.channels;
   const uint32_t count = lists[LONG ? 0 : 1];
   const uint32_t *__restrict__ list = lists + 4 + (LONG ? 0 : units);
-  const R4Geometry G4 = r4_geometry_lds(r4_geometry(lane0));          // LONG: offsets into the LDS copy
-  const SfLong SFL = sf_long_geometry(lane0);        // LONG
   const int my_size = lane0 < 52 ? kSpecs[lane0] : 0, my_long = lane0 < 52 ? kStartLong[lane0] : 0, my_short = lane0 < 52 ? kStartShort[lane0] : 0;
   const TablesRsrc RT = tables_rsrc(L.tables);
   // tails of the previous frame: lane < 24 loads four samples of band lane / 8
   const int tail_band = lane0 >> 3, tail_k = 4 * (lane0 & 7);
   const int tail_src = (tail_band == 0 ? 96 : (tail_band == 1 ? 224 : 480)) + tail_k;
-  // window values the lane needs every unit: fixed per lane, read once
-  const double wt0 = C1_TABLES(L.tables)->window[tail_k & 31], wt1 = C1_TABLES(L.tables)->window[(tail_k + 1) & 31];
-  const double wt2 = C1_TABLES(L.tables)->window[(tail_k + 2) & 31], wt3 = C1_TABLES(L.tables)->window[(tail_k + 3) & 31];
-  const double win_hi = C1_TABLES(L.tables)->window[31 - (lane0 & 31)];
+  // window values the lane needs every unit: fixed per lane -- kept in registers by the mixed instantiation, read from the
+  // shared copy where they are used by the all-long one (ten registers towards its 128)
+  double wt0 = 0.0, wt1 = 0.0, wt2 = 0.0, wt3 = 0.0;
+  if constexpr (!LONG) {
+    wt0 = C1_TABLES(L.tables)->window[tail_k & 31]; wt1 = C1_TABLES(L.tables)->window[(tail_k + 1) & 31];
+    wt2 = C1_TABLES(L.tables)->window[(tail_k + 2) & 31]; wt3 = C1_TABLES(L.tables)->window[(tail_k + 3) & 31];
+  }
   uint32_t i = blockIdx.x * kW + (uint32_t)wave;
   const uint32_t stride = gridDim.x * kW;
   if (i >= count) return;
@@ -956,8 +995,14 @@ __global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), 3) void k_md
     if (lane < 24) {
       // mdctOverlap of the previous frame (applyTailWindowing, encoder.js:309-316): W[k] * tail sample
       float4 o;
-      o.x = f32(wt0 * (double)t.x); o.y = f32(wt1 * (double)t.y);
-      o.z = f32(wt2 * (double)t.z); o.w = f32(wt3 * (double)t.w);
+      if constexpr (LONG) {
+        const double2 w01 = *reinterpret_cast<const double2 *>(&SH.win[(4 * (lane & 7)) & 31]), w23 = *reinterpret_cast<const double2 *>(&SH.win[((4 * (lane & 7)) & 31) + 2]);
+        o.x = f32(w01.x * (double)t.x); o.y = f32(w01.y * (double)t.y);
+        o.z = f32(w23.x * (double)t.z); o.w = f32(w23.y * (double)t.w);
+      } else {
+        o.x = f32(wt0 * (double)t.x); o.y = f32(wt1 * (double)t.y);
+        o.z = f32(wt2 * (double)t.z); o.w = f32(wt3 * (double)t.w);
+      }
       reinterpret_cast<float4 *>(S.ovl)[lane] = o;
     }
     wave_fence();
@@ -968,7 +1013,7 @@ __global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), 3) void k_md
       float *in0 = S.a.i.in0, *in1 = S.a.i.in1, *in2 = S.a.i.in2;
       const float *band_ = S.band;
       if (lane < 32) {
-        const double w_hi = win_hi;
+        const double w_hi = SH.win[31 - lane];
         const double x0 = band_[96 + lane], x1 = band_[128 + 96 + lane], x2 = band_[256 + 224 + lane];
         in0[48 + lane] = S.ovl[lane]; in1[48 + lane] = S.ovl[32 + lane]; in2[112 + lane] = S.ovl[64 + lane];
         in0[80 + 96 + lane] = f32(x0 * w_hi);
@@ -990,7 +1035,7 @@ __global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), 3) void k_md
         if (lane < 56) *reinterpret_cast<float4 *>(&in2[144 + 4 * lane]) = *reinterpret_cast<const float4 *>(&band_[256 + 4 * lane]);
       }
       wave_fence();
-      mdct_long_r4_t(in0, S.zz.z, coef, G4, T, LT, r4_early_t(G4, LT));
+      mdct_long_r4_t(in0, S.zz.z, coef, G4, T, LT, r4_early_t(G4, LT), &SH.late[0][0] + lane);
       wave_fence();
     } else {
       const MixGeometry GM = mix_geometry(lane, M);
@@ -1008,7 +1053,16 @@ __global__ __launch_bounds__(C1_WAVE * (LONG ? kMdctWavesLong : 1), 3) void k_md
       dst[64 + lane] = src[64 + lane];
     }
     if constexpr (LONG) {
-      sf_long(coef, S.sfi, SFL, T);
+      {
+        // the scan of sf_long from three 16-byte reads (sf_scan_long_groups), its geometry read back from the shared word
+        const uint32_t sw = SH.sfw[lane];
+        const float4 *grp = reinterpret_cast<const float4 *>(coef + (sw & 0x1fcu));
+        float mx = sf_scan_long_groups(grp[0], grp[1], grp[2]);
+        const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false));
+        mx = fmaxf(mx, ((sw >> 19) & 1u) ? other : 0.0f);
+        const int sfi = T->sf_fast ? scale_factor_index_fast(mx, T->sf_m1, T->sf_m2) : scale_factor_index(mx, T);
+        if ((sw >> 20) & 1u) S.sfi[(sw >> 13) & 63u] = (uint8_t)sfi;
+      }
       if (lane >= 60) reinterpret_cast<uint32_t *>(S.sfi)[13 + (lane - 60) % 3] = 0;   // modes byte (all long) and padding
     } else {
       if (lane < 52) {
