@@ -424,6 +424,7 @@ def main():
                                      'parity_2048_frames_mid_share_vs_oracle': ok4b}
         del pcm4, units4
         pcm = units = None
+        torch.cuda.empty_cache()      # hand the blocks back to the driver: the library sizes its chunks by what hipMemGetInfo reports free
 
     # ------------------------------------------------------------------ the other single-GPU configs (N = 1)
     if rank == 0 and world == 1 and not args.no_extras and not args.decode and args.signal == 'white' and modes == [0, 0, 0]:
@@ -476,6 +477,7 @@ def main():
         ex['tonal_partials_1M_frames'] = t
         del tone, pcm
         pcm = None
+        torch.cuda.empty_cache()
         # config 3 at its stated size: pink noise + bursts, detection on, encode + decode
         f3 = args.config3_frames
         p3 = generate(f3, 'pink', (3, 4), 0)
