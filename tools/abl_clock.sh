@@ -15,13 +15,16 @@ for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
         if sys.argv[1] in r['Kernel_Name']:
             dur[r['Dispatch_Id']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9
 busy = collections.defaultdict(float)
+valu = collections.defaultdict(float)
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if sys.argv[1] in r['Kernel_Name'] and r['Counter_Name'] == 'SQ_BUSY_CU_CYCLES':
             busy[r['Dispatch_Id']] += float(r['Counter_Value'])
+        if sys.argv[1] in r['Kernel_Name'] and r['Counter_Name'] == 'SQ_INSTS_VALU':
+            valu[r['Dispatch_Id']] += float(r['Counter_Value'])
 big = [k for k in dur if dur[k] > 0.5 * max(dur.values()) and k in busy]
-print('%-44s %s: %.0f us, clock %.3f GHz (%d launches)' % (sys.argv[2], sys.argv[1], statistics.median(dur[k] for k in big) * 1e6,
-      statistics.median(busy[k] / 256 / dur[k] / 1e9 for k in big), len(big)))
+print('%-44s %s: %.0f us, clock %.3f GHz, %.3e vector instructions (%d launches)' % (sys.argv[2], sys.argv[1], statistics.median(dur[k] for k in big) * 1e6,
+      statistics.median(busy[k] / 256 / dur[k] / 1e9 for k in big), statistics.median(valu[k] for k in big), len(big)))
 PY
 done
 rm -rf gpurun_out/abc_tmp
